@@ -1,0 +1,298 @@
+/*
+ * pathtracing_amd.h -- C ABI of the MI355X (gfx950) path-tracing core.
+ *
+ * This is the drop-in boundary for the per-pixel render loop of the
+ * mertwole/PathTracing `worker` crate.  Every entry point is `extern "C"`,
+ * takes plain pointers and sizes, never throws and never aborts across the
+ * boundary: failures come back as a non-zero PtStatus and a message readable
+ * through pt_last_error().
+ *
+ * Reference interface replaced (paths relative to the reference checkout):
+ *   trait Renderer { fn init(scene: Arc<Scene>) -> Self;
+ *                    async fn render(&mut self, Arc<RenderTask>) -> Rgb32FImage }
+ *                                           worker/src/renderer/mod.rs:9-13
+ *   its only implementor CPURenderer       worker/src/renderer/cpu_renderer/mod.rs:178-195
+ *   its only caller Worker::render          worker/src/lib.rs:31-48
+ *
+ * The structs below are the #[repr(C)] mirrors of the reference's plain f32
+ * types (math/src/lib.rs: Vec2 :118-123, Vec3 :214-220, Mat3 :369-375,
+ * Mat4 :544-551; worker/src/ray.rs:3-9; worker/src/camera.rs:35-48).
+ */
+#ifndef PATHTRACING_AMD_H
+#define PATHTRACING_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1u
+
+/* ------------------------------------------------------------------ status */
+
+typedef enum PtStatus {
+    PT_OK = 0,
+    PT_ERR_INVALID_ARGUMENT = 1, /* null pointer, bad enum, inconsistent counts        */
+    PT_ERR_SCENE = 2,            /* scene description rejected (e.g. plane axes not
+                                    orthogonal: the reference asserts, plane.rs:49-51) */
+    PT_ERR_IO = 3,               /* file missing / unreadable                           */
+    PT_ERR_PARSE = 4,            /* malformed JSON / OBJ / PNG / .tree                  */
+    PT_ERR_DEVICE = 5,           /* HIP runtime error, no device, out of memory         */
+    PT_ERR_UNSUPPORTED = 6       /* valid input the library does not handle             */
+} PtStatus;
+
+/* Copies the calling thread's last error message (NUL terminated, truncated to
+ * cap) into buf and returns the untruncated length.  Replaces the reference's
+ * panics (unwrap/expect all over worker/src). */
+size_t pt_last_error(char* buf, size_t cap);
+
+/* Library / ABI version: returns PT_ABI_VERSION of the built library. */
+uint32_t pt_abi_version(void);
+
+/* ------------------------------------------------------- math-type mirrors */
+
+typedef struct PtVec2 { float x, y; } PtVec2;                 /* math Vec2 */
+typedef struct PtVec3 { float x, y, z; } PtVec3;              /* math Vec3 */
+typedef struct PtMat3 { PtVec3 row0, row1, row2; } PtMat3;    /* math Mat3, row-major */
+typedef struct PtMat4 { float m[4][4]; } PtMat4;              /* math Mat4, m[row][col] */
+
+/* worker/src/ray.rs:3-9 */
+typedef struct PtRay {
+    PtVec3 source;
+    PtVec3 direction;
+    float min;
+    float max;
+} PtRay;
+
+/* --------------------------------------------------------------- the scene */
+
+/* Scene-graph node kinds; JSON "type" tags of the files in worker/src/scene/hierarchy/ */
+typedef enum PtNodeType {
+    PT_NODE_COLLECTION = 0, /* node_collection.rs:15-18 */
+    PT_NODE_TRANSFORM = 1,  /* transform.rs:17-25       */
+    PT_NODE_MESH = 2,       /* hierarchy/mesh.rs:18-22  */
+    PT_NODE_SPHERE = 3,     /* sphere.rs:20-29          */
+    PT_NODE_PLANE = 4,      /* plane.rs:20-28           */
+    PT_NODE_KD_TREE = 5     /* kd_tree.rs:15-19 (trace_ray is todo!() upstream; here it
+                               is "the child, accelerated": identical result to the child) */
+} PtNodeType;
+
+#define PT_NO_INDEX 0xFFFFFFFFu
+
+/* One scene-graph node.  Nodes are stored in depth-first pre-order: a node is
+ * followed by its whole first child subtree, then the next child, ...  Only the
+ * fields of the node's own type are read. */
+typedef struct PtNodeDesc {
+    uint32_t type;        /* PtNodeType */
+    uint32_t child_count; /* COLLECTION: number of children; TRANSFORM, KD_TREE: 1; leaves: 0 */
+    /* TRANSFORM */
+    PtMat4 matrix;
+    /* MESH */
+    uint32_t mesh_id;     /* index into PtSceneDesc.meshes (Scene.meshes, scene/mod.rs:44) */
+    /* MESH, SPHERE, PLANE */
+    uint32_t material_id; /* index into PtSceneDesc.materials */
+    /* SPHERE */
+    PtVec3 center;
+    float radius;
+    /* PLANE: as written in the JSON; normalised and checked for orthogonality by
+     * pt_scene_create exactly as plane.rs:45-51 does */
+    PtVec3 point, normal, tangent, bitangent;
+    /* KD_TREE: index into PtSceneDesc.trees or PT_NO_INDEX (tree is then built) */
+    uint32_t tree_id;
+} PtNodeDesc;
+
+/* A triangle mesh resource = resource::Mesh (mesh/mod.rs:19-24) before
+ * TriangleUninit::init: triangles in OBJ face order (the order is the tie-break
+ * order of the closest-hit search, mesh/mod.rs:57-62). */
+typedef struct PtMeshDesc {
+    uint64_t triangle_count;
+    const float* positions;       /* 9 floats per triangle: v0.xyz v1.xyz v2.xyz            */
+    const float* normals;         /* 9 floats per triangle, or NULL: none given              */
+    const uint8_t* normal_valid;  /* 1 byte per triangle (0: use the face normal), or NULL:
+                                     every triangle of `normals` is valid                    */
+    const float* uvs;             /* 6 floats per triangle, or NULL: (0,0) everywhere        */
+} PtMeshDesc;
+
+typedef enum PtMaterialType { PT_MATERIAL_BASE = 0, PT_MATERIAL_PBR = 1 } PtMaterialType;
+typedef enum PtUvMode { PT_UV_CLAMP = 0, PT_UV_REPEAT = 1 } PtUvMode;
+
+/* material/base.rs:25-48 and material/pbr.rs:18-35, already defaulted. */
+typedef struct PtMaterialDesc {
+    uint32_t type; /* PtMaterialType */
+    /* base */
+    uint32_t color_is_texture; /* 0: `color`, 1: texture (image_id, uv_mode) */
+    PtVec3 color;
+    uint32_t image_id;
+    uint32_t uv_mode; /* PtUvMode */
+    PtVec3 emission;
+    float refraction, reflective, emissive, refractive;
+    /* pbr */
+    PtVec3 albedo;
+    float roughness, metallic;
+} PtMaterialDesc;
+
+/* resource/image.rs: RGBA8, row-major, top row first. */
+typedef struct PtImageDesc {
+    uint32_t width, height;
+    const uint8_t* rgba8;
+} PtImageDesc;
+
+/* Serialized acceleration structure (".tree" file contents) for one mesh. */
+typedef struct PtTreeBlob {
+    const uint8_t* data;
+    uint64_t size; /* 0: empty file, build instead (scene_data/cube.tree is 0 bytes) */
+} PtTreeBlob;
+
+typedef struct PtSceneDesc {
+    const PtNodeDesc* nodes;
+    uint32_t node_count; /* nodes[0] is the root (Scene.hierarchy) */
+    const PtMeshDesc* meshes;
+    uint32_t mesh_count;
+    const PtMaterialDesc* materials;
+    uint32_t material_count;
+    const PtImageDesc* images;
+    uint32_t image_count;
+    const PtTreeBlob* trees;
+    uint32_t tree_count;
+} PtSceneDesc;
+
+typedef struct PtScene PtScene; /* opaque: device-resident scene */
+
+/* Renderer::init (renderer/mod.rs:10): validates the description, builds (or
+ * adopts) the acceleration structures, uploads everything to `device`.  All
+ * input arrays are copied; the caller keeps ownership. */
+PtStatus pt_scene_create(const PtSceneDesc* desc, int device, PtScene** out_scene);
+void pt_scene_destroy(PtScene* scene);
+
+/* ---------------------------------------------------------- the render task */
+
+typedef enum PtBokehShape { PT_BOKEH_POINT = 0, PT_BOKEH_CIRCLE = 1, PT_BOKEH_SQUARE = 2 } PtBokehShape;
+
+/* worker/src/camera.rs:35-48 */
+typedef struct PtCamera {
+    uint64_t resolution_x, resolution_y;
+    PtMat3 rotation;
+    PtVec3 position;
+    float fov; /* JSON field_of_view */
+    float near_plane;
+    float focal_length;
+    uint32_t bokeh_shape; /* PtBokehShape */
+    float bokeh_size;
+} PtCamera;
+
+/* worker/src/api/render_task.rs:23-29,45-49 minus the two strings */
+typedef struct PtRenderTask {
+    PtCamera camera;
+    uint64_t trace_depth;
+    uint64_t iterations;
+} PtRenderTask;
+
+#define PT_FLAG_BRUTE_FORCE 1u /* scan every triangle like mesh/mod.rs:57-62 (no BVH) */
+
+/* Knobs the reference does not have.  A NULL pointer means all zero. */
+typedef struct PtRenderOpts {
+    uint64_t seed;          /* key of the counter-based random stream                      */
+    uint64_t sample_offset; /* first sample index rendered (sample-range sharding)          */
+    uint32_t flags;         /* PT_FLAG_*                                                    */
+    uint32_t tile_x0, tile_y0, tile_w, tile_h; /* camera-space pixel rectangle to render
+                               (y up); w==0 or h==0: whole frame.  Pixels outside stay 0.   */
+    uint32_t paths_per_batch; /* 0: library default                                         */
+} PtRenderOpts;
+
+typedef struct PtRenderStats {
+    uint64_t rays;        /* path segments traced = iterations of work_group.rs:29-47 */
+    uint64_t paths;
+    double render_ms;     /* device time of the render itself                          */
+    uint64_t bvh_bytes;   /* device bytes of nodes + triangles of all meshes           */
+} PtRenderStats;
+
+/* Renderer::render (renderer/mod.rs:12) -> Rgb32FImage: fills out_rgb
+ * (resolution_x * resolution_y * 3 floats, row-major, top row first, i.e.
+ * already flipped like get_image, cpu_renderer/mod.rs:143-175) with
+ * sum_of_samples * (1 / iterations).  out_rgb is host memory. */
+PtStatus pt_render(PtScene* scene, const PtRenderTask* task, const PtRenderOpts* opts,
+                   float* out_rgb, PtRenderStats* stats);
+
+/* Same render, for callers that keep buffers on the GPU (sample-range sharding
+ * followed by a collective sum).  d_accum (device memory, resolution_x *
+ * resolution_y * 3 floats, camera-space layout: pixel (x,y) at (x + y*W)*3, y
+ * up) receives  d_accum += sum over this call's samples; nothing is normalised
+ * or flipped.  `stream` is a hipStream_t (NULL: the default stream); the call
+ * returns after enqueueing unless stats != NULL (then it synchronises). */
+PtStatus pt_render_accumulate_device(PtScene* scene, const PtRenderTask* task,
+                                     const PtRenderOpts* opts, float* d_accum, void* stream,
+                                     PtRenderStats* stats);
+
+/* get_image (cpu_renderer/mod.rs:143-175) on the device: d_out_rgb[(x + (H-1-y)*W)*3+c]
+ * = d_accum[(x + y*W)*3+c] * (1.0f / total_iterations). */
+PtStatus pt_resolve_device(const float* d_accum, uint64_t width, uint64_t height,
+                           uint64_t total_iterations, float* d_out_rgb, void* stream);
+
+/* ----------------------------------------------------- closest-hit contract */
+
+typedef struct PtHit {
+    uint32_t hit;        /* RayTraceResult.hit */
+    uint32_t hit_inside; /* RayTraceResult.hit_inside */
+    uint32_t node_index; /* index of the leaf node (mesh/sphere/plane) in PtSceneDesc.nodes */
+    uint32_t tri_index;  /* position in the mesh's triangle list, PT_NO_INDEX for sphere/plane */
+    uint32_t material_id;
+    float t;
+    PtVec3 point;
+    PtVec3 normal;
+    PtVec2 uv;
+} PtHit;
+
+/* scene.hierarchy.trace_ray(ray) for n rays (host arrays). */
+PtStatus pt_trace_closest(PtScene* scene, const PtRay* rays, size_t n, uint32_t flags,
+                          PtHit* out_hits);
+
+/* Camera::get_ray (camera.rs:51-83) for `n` (pixel, sample) pairs, with the
+ * library's counter-based random stream; host arrays.  pixel_xy holds n pairs
+ * (x, y) in camera space. */
+PtStatus pt_generate_rays(const PtCamera* camera, uint64_t seed, const uint32_t* pixel_xy,
+                          const uint64_t* sample_index, size_t n, int device, PtRay* out_rays);
+
+/* Material::get_color (renderer/cpu_renderer/mod.rs:50-57) for n (direction,
+ * hit) pairs with the random stream of (seed, stream_id[i]) starting at draw
+ * counter 0.  out_kind: 0 = Color, 1 = NextRayColorMultiplierAndDirection. */
+PtStatus pt_shade(PtScene* scene, const PtVec3* directions, const PtHit* hits,
+                  const uint64_t* stream_id, uint64_t seed, size_t n, uint32_t* out_kind,
+                  PtVec3* out_color_or_multiplier, PtVec3* out_direction);
+
+/* ------------------------------------------------- host-side scene loading */
+
+typedef struct PtHostScene PtHostScene; /* opaque: parsed scene files in host memory */
+
+/* Scene::load (scene/mod.rs:58-112) reading from a local directory instead of
+ * GridFS (file_store.rs:27-35): `root_dir` + "/" + path as written in the JSON.
+ * Resource ids are assigned in depth-first first-touch order like
+ * ReferenceMapping (resource/mod.rs:28-34). */
+PtStatus pt_host_scene_load(const char* root_dir, const char* scene_path, PtHostScene** out);
+const PtSceneDesc* pt_host_scene_desc(const PtHostScene* scene);
+void pt_host_scene_destroy(PtHostScene* scene);
+
+/* Parses a render task (RenderTaskUninit or RenderTask JSON text,
+ * api/render_task.rs:5-29).  scene_path_buf receives the "scene" string. */
+PtStatus pt_render_task_parse(const char* json_text, PtRenderTask* out_task,
+                              char* scene_path_buf, size_t scene_path_cap);
+
+/* ---------------------------------------------------------- .tree (de)ser. */
+
+/* Builds the acceleration structure of one mesh and serialises it.  The buffer
+ * is owned by the library: release with pt_buffer_free. */
+PtStatus pt_tree_build(const PtMeshDesc* mesh, uint8_t** out_data, uint64_t* out_size);
+void pt_buffer_free(uint8_t* data);
+
+/* ---------------------------------------------------------- result codecs */
+
+/* RenderedImage::to_bytes (worker/src/lib.rs:56-62): u32 LE width, u32 LE height,
+ * then width*height*3 f32 LE.  out must hold 8 + width*height*12 bytes. */
+PtStatus pt_rendered_image_to_bytes(const float* rgb, uint32_t width, uint32_t height,
+                                    uint8_t* out, size_t out_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PATHTRACING_AMD_H */

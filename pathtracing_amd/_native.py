@@ -1,0 +1,230 @@
+"""ctypes binding of ``libpathtracing_amd.so`` (declared in ``include/pathtracing_amd.h``).
+
+The library is the product: there is no Python or CPU fallback.  If the shared
+object has not been built, importing this module raises ``ImportError`` with the
+build command, and every compute entry point needs a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpathtracing_amd.so")
+
+PT_OK = 0
+PT_NO_INDEX = 0xFFFFFFFF
+PT_FLAG_BRUTE_FORCE = 1
+
+NODE_COLLECTION, NODE_TRANSFORM, NODE_MESH, NODE_SPHERE, NODE_PLANE, NODE_KD_TREE = range(6)
+MATERIAL_BASE, MATERIAL_PBR = 0, 1
+UV_CLAMP, UV_REPEAT = 0, 1
+BOKEH_POINT, BOKEH_CIRCLE, BOKEH_SQUARE = 0, 1, 2
+
+STATUS_NAMES = {
+    0: "PT_OK",
+    1: "PT_ERR_INVALID_ARGUMENT",
+    2: "PT_ERR_SCENE",
+    3: "PT_ERR_IO",
+    4: "PT_ERR_PARSE",
+    5: "PT_ERR_DEVICE",
+    6: "PT_ERR_UNSUPPORTED",
+}
+
+
+class PtVec2(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float)]
+
+
+class PtVec3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class PtMat3(C.Structure):
+    _fields_ = [("row0", PtVec3), ("row1", PtVec3), ("row2", PtVec3)]
+
+
+class PtMat4(C.Structure):
+    _fields_ = [("m", (C.c_float * 4) * 4)]
+
+
+class PtRay(C.Structure):
+    _fields_ = [("source", PtVec3), ("direction", PtVec3), ("min", C.c_float), ("max", C.c_float)]
+
+
+class PtNodeDesc(C.Structure):
+    _fields_ = [
+        ("type", C.c_uint32),
+        ("child_count", C.c_uint32),
+        ("matrix", PtMat4),
+        ("mesh_id", C.c_uint32),
+        ("material_id", C.c_uint32),
+        ("center", PtVec3),
+        ("radius", C.c_float),
+        ("point", PtVec3),
+        ("normal", PtVec3),
+        ("tangent", PtVec3),
+        ("bitangent", PtVec3),
+        ("tree_id", C.c_uint32),
+    ]
+
+
+class PtMeshDesc(C.Structure):
+    _fields_ = [
+        ("triangle_count", C.c_uint64),
+        ("positions", C.POINTER(C.c_float)),
+        ("normals", C.POINTER(C.c_float)),
+        ("normal_valid", C.POINTER(C.c_uint8)),
+        ("uvs", C.POINTER(C.c_float)),
+    ]
+
+
+class PtMaterialDesc(C.Structure):
+    _fields_ = [
+        ("type", C.c_uint32),
+        ("color_is_texture", C.c_uint32),
+        ("color", PtVec3),
+        ("image_id", C.c_uint32),
+        ("uv_mode", C.c_uint32),
+        ("emission", PtVec3),
+        ("refraction", C.c_float),
+        ("reflective", C.c_float),
+        ("emissive", C.c_float),
+        ("refractive", C.c_float),
+        ("albedo", PtVec3),
+        ("roughness", C.c_float),
+        ("metallic", C.c_float),
+    ]
+
+
+class PtImageDesc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgba8", C.POINTER(C.c_uint8))]
+
+
+class PtTreeBlob(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_uint8)), ("size", C.c_uint64)]
+
+
+class PtSceneDesc(C.Structure):
+    _fields_ = [
+        ("nodes", C.POINTER(PtNodeDesc)),
+        ("node_count", C.c_uint32),
+        ("meshes", C.POINTER(PtMeshDesc)),
+        ("mesh_count", C.c_uint32),
+        ("materials", C.POINTER(PtMaterialDesc)),
+        ("material_count", C.c_uint32),
+        ("images", C.POINTER(PtImageDesc)),
+        ("image_count", C.c_uint32),
+        ("trees", C.POINTER(PtTreeBlob)),
+        ("tree_count", C.c_uint32),
+    ]
+
+
+class PtCamera(C.Structure):
+    _fields_ = [
+        ("resolution_x", C.c_uint64),
+        ("resolution_y", C.c_uint64),
+        ("rotation", PtMat3),
+        ("position", PtVec3),
+        ("fov", C.c_float),
+        ("near_plane", C.c_float),
+        ("focal_length", C.c_float),
+        ("bokeh_shape", C.c_uint32),
+        ("bokeh_size", C.c_float),
+    ]
+
+
+class PtRenderTask(C.Structure):
+    _fields_ = [("camera", PtCamera), ("trace_depth", C.c_uint64), ("iterations", C.c_uint64)]
+
+
+class PtRenderOpts(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64),
+        ("sample_offset", C.c_uint64),
+        ("flags", C.c_uint32),
+        ("tile_x0", C.c_uint32),
+        ("tile_y0", C.c_uint32),
+        ("tile_w", C.c_uint32),
+        ("tile_h", C.c_uint32),
+        ("paths_per_batch", C.c_uint32),
+    ]
+
+
+class PtRenderStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("render_ms", C.c_double), ("bvh_bytes", C.c_uint64)]
+
+
+class PtHit(C.Structure):
+    _fields_ = [
+        ("hit", C.c_uint32),
+        ("hit_inside", C.c_uint32),
+        ("node_index", C.c_uint32),
+        ("tri_index", C.c_uint32),
+        ("material_id", C.c_uint32),
+        ("t", C.c_float),
+        ("point", PtVec3),
+        ("normal", PtVec3),
+        ("uv", PtVec2),
+    ]
+
+
+# Every symbol include/pathtracing_amd.h declares: name -> (restype, argtypes)
+_VOIDP = C.c_void_p
+SYMBOLS = {
+    "pt_last_error": (C.c_size_t, [C.c_char_p, C.c_size_t]),
+    "pt_abi_version": (C.c_uint32, []),
+    "pt_scene_create": (C.c_int, [C.POINTER(PtSceneDesc), C.c_int, C.POINTER(_VOIDP)]),
+    "pt_scene_destroy": (None, [_VOIDP]),
+    "pt_render": (C.c_int, [_VOIDP, C.POINTER(PtRenderTask), C.POINTER(PtRenderOpts), _VOIDP, C.POINTER(PtRenderStats)]),
+    "pt_render_accumulate_device": (
+        C.c_int,
+        [_VOIDP, C.POINTER(PtRenderTask), C.POINTER(PtRenderOpts), _VOIDP, _VOIDP, C.POINTER(PtRenderStats)],
+    ),
+    "pt_resolve_device": (C.c_int, [_VOIDP, C.c_uint64, C.c_uint64, C.c_uint64, _VOIDP, _VOIDP]),
+    "pt_trace_closest": (C.c_int, [_VOIDP, _VOIDP, C.c_size_t, C.c_uint32, _VOIDP]),
+    "pt_generate_rays": (C.c_int, [C.POINTER(PtCamera), C.c_uint64, _VOIDP, _VOIDP, C.c_size_t, C.c_int, _VOIDP]),
+    "pt_shade": (C.c_int, [_VOIDP, _VOIDP, _VOIDP, _VOIDP, C.c_uint64, C.c_size_t, _VOIDP, _VOIDP, _VOIDP]),
+    "pt_host_scene_load": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(_VOIDP)]),
+    "pt_host_scene_desc": (C.POINTER(PtSceneDesc), [_VOIDP]),
+    "pt_host_scene_destroy": (None, [_VOIDP]),
+    "pt_render_task_parse": (C.c_int, [C.c_char_p, C.POINTER(PtRenderTask), C.c_char_p, C.c_size_t]),
+    "pt_tree_build": (C.c_int, [C.POINTER(PtMeshDesc), C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]),
+    "pt_buffer_free": (None, [C.POINTER(C.c_uint8)]),
+    "pt_rendered_image_to_bytes": (C.c_int, [_VOIDP, C.c_uint32, C.c_uint32, _VOIDP, C.c_size_t]),
+}
+
+
+class PathTracingError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+        self.message = message
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C pathtracing_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError here = header and library disagree
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
+
+
+lib = _load()
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(4096)
+    lib.pt_last_error(buf, len(buf))
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(status: int) -> None:
+    if status != PT_OK:
+        raise PathTracingError(status, last_error())

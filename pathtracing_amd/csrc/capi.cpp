@@ -1,0 +1,629 @@
+// C ABI of the library (include/pathtracing_amd.h): scene upload, render,
+// closest-hit queries, host loaders.  Nothing here may throw across the boundary.
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/pathtracing_amd.h"
+#include "host/bvh.hpp"
+#include "host/host_scene.hpp"
+#include "host/xform.hpp"
+#include "kernels/pt_kernels.h"
+
+namespace pt {
+const std::string& last_error_string();
+}
+
+using pt::Error;
+
+namespace {
+
+void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess)
+        throw Error(PT_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+template <class F> PtStatus guarded(F f) {
+    try {
+        f();
+        return PT_OK;
+    } catch (const Error& e) {
+        pt::set_last_error(e.what());
+        return e.status;
+    } catch (const std::bad_alloc&) {
+        pt::set_last_error("out of host memory");
+        return PT_ERR_DEVICE;
+    } catch (const std::exception& e) {
+        pt::set_last_error(e.what());
+        return PT_ERR_PARSE;
+    } catch (...) {
+        pt::set_last_error("unknown failure");
+        return PT_ERR_INVALID_ARGUMENT;
+    }
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        hip_check(hipGetDevice(&prev), "hipGetDevice");
+        if (prev != dev) hip_check(hipSetDevice(dev), "hipSetDevice");
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+} // namespace
+
+struct PtScene {
+    int device = 0;
+    ptk::DScene d{};
+    std::vector<void*> allocs;
+    ptk::Workspace ws;
+    uint64_t bvh_bytes = 0;
+    uint32_t node_count = 0;
+    std::vector<uint32_t> mesh_tri_count;
+
+    void* dev_alloc(size_t bytes) {
+        void* p = nullptr;
+        hip_check(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc");
+        allocs.push_back(p);
+        return p;
+    }
+    template <class T> T* upload(const std::vector<T>& v) {
+        T* p = static_cast<T*>(dev_alloc(v.size() * sizeof(T)));
+        if (!v.empty()) hip_check(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy H2D");
+        return p;
+    }
+    void free_workspace() {
+        for (int q = 0; q < 2; q++)
+            for (int k = 0; k < 3; k++)
+                if (ws.queue[q][k]) {
+                    (void)hipFree(ws.queue[q][k]);
+                    ws.queue[q][k] = nullptr;
+                }
+        if (ws.contrib) (void)hipFree(ws.contrib);
+        ws.contrib = nullptr;
+        ws.capacity_paths = 0;
+    }
+    void ensure_workspace(uint64_t paths) {
+        if (!ws.counters) {
+            hip_check(hipMalloc(reinterpret_cast<void**>(&ws.counters), sizeof(uint32_t) * ptk::kMaxDepthCounters),
+                      "hipMalloc counters");
+            hip_check(hipMalloc(reinterpret_cast<void**>(&ws.ray_total), sizeof(uint64_t)), "hipMalloc ray_total");
+        }
+        if (paths <= ws.capacity_paths) return;
+        free_workspace();
+        for (int q = 0; q < 2; q++)
+            for (int k = 0; k < 3; k++)
+                hip_check(hipMalloc(reinterpret_cast<void**>(&ws.queue[q][k]), paths * sizeof(float4)), "hipMalloc queue");
+        hip_check(hipMalloc(reinterpret_cast<void**>(&ws.contrib), paths * 3 * sizeof(float)), "hipMalloc contrib");
+        ws.capacity_paths = paths;
+    }
+    ~PtScene() {
+        free_workspace();
+        if (ws.counters) (void)hipFree(ws.counters);
+        if (ws.ray_total) (void)hipFree(ws.ray_total);
+        for (void* p : allocs) (void)hipFree(p);
+    }
+};
+
+struct PtHostScene {
+    std::unique_ptr<pt::HostScene> scene;
+};
+
+namespace {
+
+ptk::V3 v3(const PtVec3& p) { return ptk::mk3(p.x, p.y, p.z); }
+
+// Checks the pre-order node array and fills end / parent / depth.
+void layout_nodes(const PtSceneDesc& d, std::vector<ptk::DNode>& out) {
+    out.assign(d.node_count, ptk::DNode{});
+    struct Open {
+        uint32_t node;
+        uint32_t remaining;
+        bool frame; // collection or transform (kd_tree is transparent)
+    };
+    std::vector<Open> stack;
+    for (uint32_t i = 0; i < d.node_count; i++) {
+        const PtNodeDesc& nd = d.nodes[i];
+        if (stack.empty() && i != 0) throw Error(PT_ERR_SCENE, "node array has entries after the root subtree");
+        uint32_t parent = 0xFFFFFFFFu, depth = 0;
+        for (const Open& o : stack)
+            if (o.frame) {
+                parent = o.node;
+                depth++;
+            }
+        ptk::DNode& o = out[i];
+        o.type = nd.type;
+        o.parent = parent;
+        o.depth = depth;
+        o.material_id = 0;
+        o.mesh_id = 0;
+        uint32_t children = 0;
+        bool frame = false;
+        switch (nd.type) {
+        case PT_NODE_COLLECTION:
+            children = nd.child_count;
+            frame = true;
+            break;
+        case PT_NODE_TRANSFORM: {
+            children = 1;
+            frame = true;
+            memcpy(o.matrix.m, nd.matrix.m, sizeof(o.matrix.m));
+            o.matrix_inverse = pt::inverse4(o.matrix);
+            o.normal_matrix = pt::normal_matrix4(o.matrix);
+            o.inverse_normal_matrix = pt::normal_matrix4(o.matrix_inverse);
+            break;
+        }
+        case PT_NODE_KD_TREE: children = 1; break;
+        case PT_NODE_MESH:
+            if (nd.mesh_id >= d.mesh_count) throw Error(PT_ERR_SCENE, "mesh node references a missing mesh");
+            if (nd.material_id >= d.material_count) throw Error(PT_ERR_SCENE, "mesh node references a missing material");
+            o.mesh_id = nd.mesh_id;
+            o.material_id = nd.material_id;
+            break;
+        case PT_NODE_SPHERE:
+            if (nd.material_id >= d.material_count) throw Error(PT_ERR_SCENE, "sphere references a missing material");
+            o.center = v3(nd.center);
+            o.radius = nd.radius;
+            o.radius_sqr = nd.radius * nd.radius; // sphere.rs:51
+            o.material_id = nd.material_id;
+            break;
+        case PT_NODE_PLANE: {
+            if (nd.material_id >= d.material_count) throw Error(PT_ERR_SCENE, "plane references a missing material");
+            // plane.rs:45-51
+            o.point = v3(nd.point);
+            o.normal = ptk::normalized(v3(nd.normal));
+            o.tangent = ptk::normalized(v3(nd.tangent));
+            o.bitangent = ptk::normalized(v3(nd.bitangent));
+            bool ok = std::fabs(ptk::dot(o.normal, o.tangent)) < 0.001f &&
+                      std::fabs(ptk::dot(o.normal, o.bitangent)) < 0.001f &&
+                      std::fabs(ptk::dot(o.tangent, o.bitangent)) < 0.001f;
+            if (!ok) throw Error(PT_ERR_SCENE, "plane normal/tangent/bitangent are not pairwise orthogonal");
+            o.material_id = nd.material_id;
+            break;
+        }
+        default: throw Error(PT_ERR_SCENE, "unknown node type");
+        }
+        if (frame && depth + 1 > (uint32_t)ptk::kMaxGraphDepth)
+            throw Error(PT_ERR_UNSUPPORTED, "scene graph nests collections/transforms deeper than 8");
+        // this node is one child of the innermost open node
+        if (!stack.empty()) stack.back().remaining--;
+        if (children > 0) {
+            stack.push_back({i, children, frame});
+        } else {
+            o.end = i + 1;
+            if (nd.type == PT_NODE_COLLECTION) o.end = i + 1; // empty collection
+        }
+        // close every open node whose children are all placed
+        while (!stack.empty() && stack.back().remaining == 0) {
+            out[stack.back().node].end = i + 1;
+            stack.pop_back();
+        }
+    }
+    if (!stack.empty()) throw Error(PT_ERR_SCENE, "node array ends inside a subtree");
+}
+
+void build_mesh(PtScene& s, const PtMeshDesc& m, const PtTreeBlob* blob, ptk::DMesh* out) {
+    if (m.triangle_count && !m.positions) throw Error(PT_ERR_INVALID_ARGUMENT, "mesh without positions");
+    if (m.triangle_count >= (1ull << 28)) throw Error(PT_ERR_UNSUPPORTED, "mesh has too many triangles");
+    const uint64_t n = m.triangle_count;
+    pt::BuiltBvh bvh;
+    bool adopted = false;
+    if (blob && blob->size && blob->data) adopted = pt::deserialize_tree(blob->data, blob->size, m.positions, n, &bvh);
+    if (!adopted) bvh = pt::build_bvh(m.positions, n, 4);
+
+    std::vector<ptk::LeafTri> leaf(n), orig(n);
+    std::vector<ptk::ShadeTri> shade(n);
+    for (uint64_t i = 0; i < n; i++) {
+        const float* p = m.positions + 9 * i;
+        ptk::LeafTri& t = orig[i];
+        memcpy(t.v0, p, 12);
+        memcpy(t.v1, p + 3, 12);
+        memcpy(t.v2, p + 6, 12);
+        t.orig_index = (uint32_t)i;
+        t.pad1 = t.pad2 = 0;
+        // TriangleUninit::init, triangle/mod.rs:65-84
+        ptk::V3 v0 = ptk::ld3(p), v1 = ptk::ld3(p + 3), v2 = ptk::ld3(p + 6);
+        ptk::V3 tn = ptk::normalized(ptk::cross(v1 - v0, v1 - v2));
+        ptk::ShadeTri& sh = shade[i];
+        memset(&sh, 0, sizeof(sh));
+        sh.true_normal[0] = tn.x;
+        sh.true_normal[1] = tn.y;
+        sh.true_normal[2] = tn.z;
+        bool has_n = m.normals && (!m.normal_valid || m.normal_valid[i]);
+        float* dstn[3] = {sh.n0, sh.n1, sh.n2};
+        float* dstuv[3] = {sh.uv0, sh.uv1, sh.uv2};
+        for (int v = 0; v < 3; v++) {
+            if (has_n) memcpy(dstn[v], m.normals + 9 * i + 3 * v, 12);
+            else memcpy(dstn[v], sh.true_normal, 12);
+            if (m.uvs) memcpy(dstuv[v], m.uvs + 6 * i + 2 * v, 8);
+        }
+    }
+    for (uint64_t k = 0; k < n; k++) leaf[k] = orig[bvh.order[k]];
+
+    out->nodes = s.upload(bvh.nodes);
+    out->tris = s.upload(leaf);
+    out->tris_orig = s.upload(orig);
+    out->shade = s.upload(shade);
+    out->tri_count = (uint32_t)n;
+    out->node_count = (uint32_t)bvh.nodes.size();
+    out->root_ref = bvh.root_ref;
+    out->pad = 0;
+    memcpy(out->bmin, bvh.bmin, sizeof(out->bmin));
+    memcpy(out->bmax, bvh.bmax, sizeof(out->bmax));
+    s.bvh_bytes += bvh.nodes.size() * sizeof(ptk::BvhNode) + n * sizeof(ptk::LeafTri);
+}
+
+ptk::DCamera make_camera(const PtCamera& c) {
+    if (c.resolution_x == 0 || c.resolution_y == 0) throw Error(PT_ERR_INVALID_ARGUMENT, "camera resolution is zero");
+    if (c.resolution_x > 65536 || c.resolution_y > 65536) throw Error(PT_ERR_UNSUPPORTED, "camera resolution above 65536");
+    if (c.bokeh_shape > PT_BOKEH_SQUARE) throw Error(PT_ERR_INVALID_ARGUMENT, "unknown bokeh shape");
+    ptk::DCamera d;
+    d.width = (uint32_t)c.resolution_x;
+    d.height = (uint32_t)c.resolution_y;
+    d.res_x = (float)c.resolution_x;
+    d.res_y = (float)c.resolution_y;
+    d.rotation.row0 = v3(c.rotation.row0);
+    d.rotation.row1 = v3(c.rotation.row1);
+    d.rotation.row2 = v3(c.rotation.row2);
+    d.position = v3(c.position);
+    d.focal_length = c.focal_length;
+    d.near_plane = c.near_plane;
+    d.bokeh_size = c.bokeh_size;
+    d.bokeh_shape = c.bokeh_shape;
+    // camera.rs:56-57
+    d.viewport_x = c.focal_length * tanf(c.fov * 0.5f) * 2.0f;
+    d.viewport_y = d.viewport_x * (d.res_y / d.res_x);
+    return d;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    explicit DevBuf(size_t bytes) { hip_check(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc"); }
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderOpts* opts_in, float* d_accum,
+                       hipStream_t stream, PtRenderStats* stats) {
+    if (!scene || !task || !d_accum) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+    PtRenderOpts o;
+    memset(&o, 0, sizeof(o));
+    if (opts_in) o = *opts_in;
+    ptk::DCamera cam = make_camera(task->camera);
+    if (task->trace_depth + 1 > ptk::kMaxDepthCounters) throw Error(PT_ERR_UNSUPPORTED, "trace_depth above 4094");
+    if (o.sample_offset + task->iterations > 0xFFFFFFFFull) throw Error(PT_ERR_UNSUPPORTED, "sample index above 2^32");
+    uint32_t x0 = 0, y0 = 0, w = cam.width, h = cam.height;
+    if (o.tile_w && o.tile_h) {
+        if (o.tile_x0 >= cam.width || o.tile_y0 >= cam.height) throw Error(PT_ERR_INVALID_ARGUMENT, "tile outside the frame");
+        x0 = o.tile_x0;
+        y0 = o.tile_y0;
+        w = std::min(o.tile_w, cam.width - x0);
+        h = std::min(o.tile_h, cam.height - y0);
+    }
+    uint64_t budget = o.paths_per_batch ? o.paths_per_batch : (16ull << 20);
+    if (budget < 64) budget = 64;
+    // Bands of whole 8-pixel rows such that one sample of a band fits the budget.
+    uint32_t nbx = (w + 7) / 8;
+    uint64_t slots_per_block_row = (uint64_t)nbx * 64;
+    uint32_t band_block_rows = (uint32_t)std::max<uint64_t>(1, budget / slots_per_block_row);
+    uint32_t total_block_rows = (h + 7) / 8;
+    if (band_block_rows > total_block_rows) band_block_rows = total_block_rows;
+    uint64_t band_slots = (uint64_t)band_block_rows * slots_per_block_row;
+    uint32_t samples_per_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / band_slots, task->iterations ? task->iterations : 1));
+    scene->ensure_workspace(band_slots * samples_per_batch);
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (stats) {
+        hip_check(hipEventCreate(&ev0), "hipEventCreate");
+        hip_check(hipEventCreate(&ev1), "hipEventCreate");
+        hip_check(hipMemsetAsync(scene->ws.ray_total, 0, sizeof(uint64_t), stream), "hipMemsetAsync");
+        hip_check(hipEventRecord(ev0, stream), "hipEventRecord");
+    }
+    bool brute = (o.flags & PT_FLAG_BRUTE_FORCE) != 0;
+    uint64_t paths = 0;
+    for (uint32_t br = 0; br < total_block_rows; br += band_block_rows) {
+        ptk::BatchGeometry g;
+        g.x0 = x0;
+        g.y0 = y0 + br * 8;
+        g.w = w;
+        g.h = std::min<uint32_t>(band_block_rows * 8, h - br * 8);
+        g.nbx = nbx;
+        g.nby = (g.h + 7) / 8;
+        g.npp = g.nbx * g.nby * 64;
+        for (uint64_t s = 0; s < task->iterations; s += samples_per_batch) {
+            uint32_t cnt = (uint32_t)std::min<uint64_t>(samples_per_batch, task->iterations - s);
+            hip_check(ptk::render_batch(scene->d, cam, g, o.seed, o.sample_offset + s, cnt, (uint32_t)task->trace_depth,
+                                        brute, scene->ws, d_accum, stream),
+                      "render_batch");
+            paths += (uint64_t)cnt * g.w * g.h;
+        }
+    }
+    if (stats) {
+        hip_check(hipEventRecord(ev1, stream), "hipEventRecord");
+        hip_check(hipEventSynchronize(ev1), "hipEventSynchronize");
+        float ms = 0.0f;
+        hip_check(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime");
+        uint64_t rays = 0;
+        hip_check(hipMemcpy(&rays, scene->ws.ray_total, sizeof(rays), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+        (void)hipEventDestroy(ev0);
+        (void)hipEventDestroy(ev1);
+        stats->rays = task->trace_depth ? rays : 0;
+        stats->paths = paths;
+        stats->render_ms = ms;
+        stats->bvh_bytes = scene->bvh_bytes;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+size_t pt_last_error(char* buf, size_t cap) {
+    const std::string& e = pt::last_error_string();
+    if (buf && cap) {
+        size_t n = std::min(cap - 1, e.size());
+        memcpy(buf, e.data(), n);
+        buf[n] = 0;
+    }
+    return e.size();
+}
+
+uint32_t pt_abi_version(void) { return PT_ABI_VERSION; }
+
+PtStatus pt_scene_create(const PtSceneDesc* desc, int device, PtScene** out_scene) {
+    return guarded([&] {
+        if (!desc || !out_scene) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        if (!desc->nodes || desc->node_count == 0) throw Error(PT_ERR_SCENE, "scene has no nodes");
+        if ((desc->mesh_count && !desc->meshes) || (desc->material_count && !desc->materials) ||
+            (desc->image_count && !desc->images) || (desc->tree_count && !desc->trees))
+            throw Error(PT_ERR_INVALID_ARGUMENT, "count without array");
+        int ndev = 0;
+        hip_check(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
+        if (device < 0 || device >= ndev) throw Error(PT_ERR_DEVICE, "no such HIP device");
+        DeviceGuard guard(device);
+        auto s = std::make_unique<PtScene>();
+        s->device = device;
+
+        std::vector<ptk::DNode> nodes;
+        layout_nodes(*desc, nodes);
+        s->node_count = desc->node_count;
+
+        // a kd_tree node directly above a mesh node offers its .tree blob to that mesh
+        std::vector<const PtTreeBlob*> mesh_blob(desc->mesh_count, nullptr);
+        for (uint32_t i = 0; i + 1 < desc->node_count; i++) {
+            const PtNodeDesc& nd = desc->nodes[i];
+            if (nd.type == PT_NODE_KD_TREE && desc->nodes[i + 1].type == PT_NODE_MESH && nd.tree_id != PT_NO_INDEX) {
+                if (nd.tree_id >= desc->tree_count) throw Error(PT_ERR_SCENE, "kd_tree node references a missing tree");
+                mesh_blob[desc->nodes[i + 1].mesh_id] = &desc->trees[nd.tree_id];
+            }
+        }
+        std::vector<ptk::DMesh> meshes(desc->mesh_count);
+        for (uint32_t i = 0; i < desc->mesh_count; i++) {
+            build_mesh(*s, desc->meshes[i], mesh_blob[i], &meshes[i]);
+            s->mesh_tri_count.push_back((uint32_t)desc->meshes[i].triangle_count);
+        }
+
+        std::vector<const uint8_t*> texels(desc->image_count, nullptr);
+        for (uint32_t i = 0; i < desc->image_count; i++) {
+            const PtImageDesc& im = desc->images[i];
+            if (!im.rgba8 || im.width == 0 || im.height == 0) throw Error(PT_ERR_SCENE, "empty image");
+            size_t bytes = (size_t)im.width * im.height * 4;
+            void* p = s->dev_alloc(bytes);
+            hip_check(hipMemcpy(p, im.rgba8, bytes, hipMemcpyHostToDevice), "hipMemcpy image");
+            texels[i] = static_cast<const uint8_t*>(p);
+        }
+        std::vector<ptk::DMaterial> mats(desc->material_count);
+        for (uint32_t i = 0; i < desc->material_count; i++) {
+            const PtMaterialDesc& m = desc->materials[i];
+            ptk::DMaterial& d = mats[i];
+            memset(&d, 0, sizeof(d));
+            if (m.type > PT_MATERIAL_PBR) throw Error(PT_ERR_SCENE, "unknown material type");
+            d.type = m.type;
+            d.color_is_texture = (m.type == PT_MATERIAL_BASE && m.color_is_texture) ? 1u : 0u;
+            if (d.color_is_texture) {
+                if (m.image_id >= desc->image_count) throw Error(PT_ERR_SCENE, "material references a missing image");
+                if (m.uv_mode > PT_UV_REPEAT) throw Error(PT_ERR_SCENE, "unknown uv mode");
+                d.texels = texels[m.image_id];
+                d.tex_w = desc->images[m.image_id].width;
+                d.tex_h = desc->images[m.image_id].height;
+                d.uv_mode = m.uv_mode;
+            }
+            d.color = v3(m.color);
+            d.emission = v3(m.emission);
+            d.refraction = m.refraction;
+            d.reflective = m.reflective;
+            d.emissive = m.emissive;
+            d.refractive = m.refractive;
+            d.albedo = v3(m.albedo);
+            d.roughness = m.roughness;
+            d.metallic = m.metallic;
+            // pbr.rs:92-96
+            d.f0 = d.albedo * m.metallic + ptk::splat3(0.04f) * (1.0f - m.metallic);
+            d.roughness_sqr = m.roughness * m.roughness;
+        }
+        s->d.nodes = s->upload(nodes);
+        s->d.node_count = desc->node_count;
+        s->d.meshes = s->upload(meshes);
+        s->d.materials = s->upload(mats);
+        s->d.mesh_count = desc->mesh_count;
+        s->d.material_count = desc->material_count;
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        *out_scene = s.release();
+    });
+}
+
+void pt_scene_destroy(PtScene* scene) {
+    if (!scene) return;
+    try {
+        DeviceGuard guard(scene->device);
+        delete scene;
+    } catch (...) {
+    }
+}
+
+PtStatus pt_render_accumulate_device(PtScene* scene, const PtRenderTask* task, const PtRenderOpts* opts, float* d_accum,
+                                     void* stream, PtRenderStats* stats) {
+    return guarded([&] {
+        if (!scene) throw Error(PT_ERR_INVALID_ARGUMENT, "null scene");
+        DeviceGuard guard(scene->device);
+        render_accumulate(scene, task, opts, d_accum, static_cast<hipStream_t>(stream), stats);
+    });
+}
+
+PtStatus pt_resolve_device(const float* d_accum, uint64_t width, uint64_t height, uint64_t total_iterations,
+                           float* d_out_rgb, void* stream) {
+    return guarded([&] {
+        if (!d_accum || !d_out_rgb) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        if (width == 0 || height == 0 || width > 65536 || height > 65536) throw Error(PT_ERR_INVALID_ARGUMENT, "bad image size");
+        // work_group.rs:67-69: 1.0 / (iteration as f32)
+        float scale = 1.0f / (float)total_iterations;
+        hip_check(ptk::resolve_image(d_accum, (uint32_t)width, (uint32_t)height, scale, d_out_rgb,
+                                     static_cast<hipStream_t>(stream)),
+                  "resolve_image");
+    });
+}
+
+PtStatus pt_render(PtScene* scene, const PtRenderTask* task, const PtRenderOpts* opts, float* out_rgb,
+                   PtRenderStats* stats) {
+    return guarded([&] {
+        if (!scene || !task || !out_rgb) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        DeviceGuard guard(scene->device);
+        (void)make_camera(task->camera);
+        size_t floats = (size_t)task->camera.resolution_x * task->camera.resolution_y * 3;
+        DevBuf accum(floats * sizeof(float)), out(floats * sizeof(float));
+        hip_check(hipMemsetAsync(accum.p, 0, floats * sizeof(float), nullptr), "hipMemsetAsync");
+        PtRenderStats local;
+        memset(&local, 0, sizeof(local));
+        render_accumulate(scene, task, opts, static_cast<float*>(accum.p), nullptr, stats ? stats : &local);
+        float scale = 1.0f / (float)task->iterations;
+        hip_check(ptk::resolve_image(static_cast<float*>(accum.p), (uint32_t)task->camera.resolution_x,
+                                     (uint32_t)task->camera.resolution_y, scale, static_cast<float*>(out.p), nullptr),
+                  "resolve_image");
+        hip_check(hipMemcpy(out_rgb, out.p, floats * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+    });
+}
+
+PtStatus pt_trace_closest(PtScene* scene, const PtRay* rays, size_t n, uint32_t flags, PtHit* out_hits) {
+    return guarded([&] {
+        if (!scene || (n && (!rays || !out_hits))) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        if (n == 0) return;
+        DeviceGuard guard(scene->device);
+        DevBuf d_rays(n * sizeof(PtRay)), d_hits(n * sizeof(PtHit));
+        hip_check(hipMemcpy(d_rays.p, rays, n * sizeof(PtRay), hipMemcpyHostToDevice), "hipMemcpy H2D");
+        hip_check(ptk::trace_closest(scene->d, static_cast<const PtRay*>(d_rays.p), n, (flags & PT_FLAG_BRUTE_FORCE) != 0,
+                                     static_cast<PtHit*>(d_hits.p), nullptr),
+                  "trace_closest");
+        hip_check(hipMemcpy(out_hits, d_hits.p, n * sizeof(PtHit), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+    });
+}
+
+PtStatus pt_generate_rays(const PtCamera* camera, uint64_t seed, const uint32_t* pixel_xy, const uint64_t* sample_index,
+                          size_t n, int device, PtRay* out_rays) {
+    return guarded([&] {
+        if (!camera || (n && (!pixel_xy || !sample_index || !out_rays))) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        if (n == 0) return;
+        ptk::DCamera cam = make_camera(*camera);
+        for (size_t i = 0; i < n; i++)
+            if (pixel_xy[2 * i] >= cam.width || pixel_xy[2 * i + 1] >= cam.height)
+                throw Error(PT_ERR_INVALID_ARGUMENT, "pixel outside the frame");
+        DeviceGuard guard(device);
+        DevBuf d_px(n * 8), d_s(n * 8), d_r(n * sizeof(PtRay));
+        hip_check(hipMemcpy(d_px.p, pixel_xy, n * 8, hipMemcpyHostToDevice), "hipMemcpy H2D");
+        hip_check(hipMemcpy(d_s.p, sample_index, n * 8, hipMemcpyHostToDevice), "hipMemcpy H2D");
+        hip_check(ptk::generate_rays(cam, seed, static_cast<const uint32_t*>(d_px.p), static_cast<const uint64_t*>(d_s.p), n,
+                                     static_cast<PtRay*>(d_r.p), nullptr),
+                  "generate_rays");
+        hip_check(hipMemcpy(out_rays, d_r.p, n * sizeof(PtRay), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+    });
+}
+
+PtStatus pt_shade(PtScene* scene, const PtVec3* directions, const PtHit* hits, const uint64_t* stream_id, uint64_t seed,
+                  size_t n, uint32_t* out_kind, PtVec3* out_a, PtVec3* out_direction) {
+    return guarded([&] {
+        if (!scene || (n && (!directions || !hits || !stream_id || !out_kind || !out_a || !out_direction)))
+            throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        if (n == 0) return;
+        for (size_t i = 0; i < n; i++)
+            if (hits[i].material_id >= scene->d.material_count) throw Error(PT_ERR_INVALID_ARGUMENT, "material id out of range");
+        DeviceGuard guard(scene->device);
+        DevBuf d_dir(n * sizeof(PtVec3)), d_hit(n * sizeof(PtHit)), d_sid(n * 8), d_kind(n * 4), d_a(n * sizeof(PtVec3)),
+            d_o(n * sizeof(PtVec3));
+        hip_check(hipMemcpy(d_dir.p, directions, n * sizeof(PtVec3), hipMemcpyHostToDevice), "hipMemcpy H2D");
+        hip_check(hipMemcpy(d_hit.p, hits, n * sizeof(PtHit), hipMemcpyHostToDevice), "hipMemcpy H2D");
+        hip_check(hipMemcpy(d_sid.p, stream_id, n * 8, hipMemcpyHostToDevice), "hipMemcpy H2D");
+        hip_check(ptk::shade(scene->d, static_cast<const PtVec3*>(d_dir.p), static_cast<const PtHit*>(d_hit.p),
+                             static_cast<const uint64_t*>(d_sid.p), seed, n, static_cast<uint32_t*>(d_kind.p),
+                             static_cast<PtVec3*>(d_a.p), static_cast<PtVec3*>(d_o.p), nullptr),
+                  "shade");
+        hip_check(hipMemcpy(out_kind, d_kind.p, n * 4, hipMemcpyDeviceToHost), "hipMemcpy D2H");
+        hip_check(hipMemcpy(out_a, d_a.p, n * sizeof(PtVec3), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+        hip_check(hipMemcpy(out_direction, d_o.p, n * sizeof(PtVec3), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+    });
+}
+
+PtStatus pt_host_scene_load(const char* root_dir, const char* scene_path, PtHostScene** out) {
+    return guarded([&] {
+        if (!root_dir || !scene_path || !out) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        pt::FileStore store(root_dir);
+        auto hs = std::make_unique<PtHostScene>();
+        hs->scene = pt::load_scene(store, scene_path);
+        *out = hs.release();
+    });
+}
+
+const PtSceneDesc* pt_host_scene_desc(const PtHostScene* scene) { return scene ? &scene->scene->desc : nullptr; }
+
+void pt_host_scene_destroy(PtHostScene* scene) { delete scene; }
+
+PtStatus pt_render_task_parse(const char* json_text, PtRenderTask* out_task, char* scene_path_buf, size_t scene_path_cap) {
+    return guarded([&] {
+        if (!json_text || !out_task) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        std::string path;
+        pt::parse_render_task(json_text, out_task, &path);
+        if (scene_path_buf && scene_path_cap) {
+            if (path.size() + 1 > scene_path_cap) throw Error(PT_ERR_INVALID_ARGUMENT, "scene path buffer too small");
+            memcpy(scene_path_buf, path.c_str(), path.size() + 1);
+        }
+    });
+}
+
+PtStatus pt_tree_build(const PtMeshDesc* mesh, uint8_t** out_data, uint64_t* out_size) {
+    return guarded([&] {
+        if (!mesh || !out_data || !out_size || (mesh->triangle_count && !mesh->positions))
+            throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        pt::BuiltBvh bvh = pt::build_bvh(mesh->positions, mesh->triangle_count, 4);
+        std::vector<uint8_t> blob = pt::serialize_tree(bvh, mesh->positions, mesh->triangle_count);
+        uint8_t* p = static_cast<uint8_t*>(malloc(blob.size() ? blob.size() : 1));
+        if (!p) throw std::bad_alloc();
+        memcpy(p, blob.data(), blob.size());
+        *out_data = p;
+        *out_size = blob.size();
+    });
+}
+
+void pt_buffer_free(uint8_t* data) { free(data); }
+
+PtStatus pt_rendered_image_to_bytes(const float* rgb, uint32_t width, uint32_t height, uint8_t* out, size_t out_cap) {
+    return guarded([&] {
+        if (!rgb || !out) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        size_t floats = (size_t)width * height * 3;
+        if (out_cap < 8 + floats * 4) throw Error(PT_ERR_INVALID_ARGUMENT, "output buffer too small");
+        // lib.rs:56-62; this target is little-endian, so the f32 bytes are copied as they are
+        memcpy(out, &width, 4);
+        memcpy(out + 4, &height, 4);
+        memcpy(out + 8, rgb, floats * 4);
+    });
+}
+
+} // extern "C"

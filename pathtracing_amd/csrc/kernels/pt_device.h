@@ -1,0 +1,589 @@
+// Device functions of the path-tracing hot path: random stream, camera ray,
+// primitive intersection, BVH traversal, scene-graph walk and material sampling.
+// Each function cites the reference code whose arithmetic it reproduces; the
+// translation unit must be built with -ffp-contract=off.
+#pragma once
+#include "../pt_portable_math.h"
+#include "pt_scene_device.h"
+
+namespace ptk {
+
+// ------------------------------------------------------------------ random stream
+// The reference draws from an unseeded rand 0.8 thread_rng() (camera.rs:21,28,52;
+// material/base.rs:94,114,133-134; material/pbr.rs:109-112).  This stream is
+// counter based instead: draw c (1-based) of stream s under seed k is the high
+// 32 bits of mix64(key + c*G), key = mix64(mix64(k + G) ^ s), mix64 = SplitMix64
+// finaliser.  gen_range keeps rand's f32 lattice: u = (draw >> 9) * 2^-23,
+// value = u*(hi-lo) + lo.
+constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ull;
+PT_HD uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+PT_HD uint64_t stream_key(uint64_t seed, uint64_t stream) { return mix64(mix64(seed + kGolden) ^ stream); }
+PT_HD uint64_t stream_id(uint64_t sample, uint64_t pixel_linear) { return (sample << 32) | pixel_linear; }
+
+struct Rng {
+    uint64_t key;
+    uint32_t counter;
+    PT_HD uint32_t next_u32() {
+        counter++;
+        return (uint32_t)(mix64(key + (uint64_t)counter * kGolden) >> 32);
+    }
+    PT_HD float gen_range(float lo, float hi) {
+        float scale = hi - lo;
+        float u = (float)(next_u32() >> 9) * 1.1920928955078125e-7f;
+        return u * scale + lo;
+    }
+    PT_HD bool gen_bool_half() { return (next_u32() >> 31) == 0u; }
+};
+
+// ------------------------------------------------------------------ camera
+// camera.rs:16-33 (BokehShape::sample) and :51-83 (Camera::get_ray)
+PT_HD Ray camera_get_ray(const DCamera& cam, uint32_t px, uint32_t py, Rng& rng) {
+    float x_offset = rng.gen_range(-0.5f, 0.5f);
+    float y_offset = rng.gen_range(-0.5f, 0.5f);
+    V3 watch_dot = cam.position;
+    watch_dot.x += (((float)px + x_offset) / cam.res_x - 0.5f) * cam.viewport_x;
+    watch_dot.y += (((float)py + y_offset) / cam.res_y - 0.5f) * cam.viewport_y;
+    watch_dot.z -= cam.focal_length;
+    V3 point_on_objective = cam.position;
+    V2 sample = mk2(0.0f, 0.0f);
+    if (cam.bokeh_shape == 1u) { // circle
+        float phi = rng.gen_range(0.0f, 2.0f * kPi);
+        float r = sqrt_rn(rng.gen_range(0.0f, 1.0f));
+        sample = mk2(ptm::cos_f32(phi), ptm::sin_f32(phi)) * r;
+    } else if (cam.bokeh_shape == 2u) { // square
+        float sx = rng.gen_range(-0.5f, 0.5f);
+        float sy = rng.gen_range(-0.5f, 0.5f);
+        sample = mk2(sx, sy);
+    }
+    V2 objective_sample = sample * cam.bokeh_size;
+    point_on_objective.x += objective_sample.x;
+    point_on_objective.y += objective_sample.y;
+    V3 direction = mul(cam.rotation, watch_dot - point_on_objective);
+    float near_plane_dist = length(direction) / cam.focal_length * cam.near_plane;
+    Ray r;
+    r.source = point_on_objective;
+    r.direction = normalized(direction);
+    r.min = near_plane_dist;
+    r.max = kF32Max;
+    return r;
+}
+
+// ------------------------------------------------------------------ triangle
+// Moller-Trumbore exactly as triangle/mod.rs:130-157.  Returns true and t when
+// the reference would report a hit.
+PT_HD bool triangle_hit(V3 v0, V3 v1, V3 v2, const Ray& ray, float* t_out) {
+    V3 edge0 = v1 - v0;
+    V3 edge1 = v2 - v0;
+    V3 pvec = cross(ray.direction, edge1);
+    float determinant = dot(edge0, pvec);
+    if (determinant < kEpsilon && determinant > -kEpsilon) return false;
+    float inv_determinant = 1.0f / determinant;
+    V3 tvec = ray.source - v0;
+    float u = dot(tvec, pvec) * inv_determinant;
+    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    V3 qvec = cross(tvec, edge0);
+    float v = dot(ray.direction, qvec) * inv_determinant;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = dot(edge1, qvec) * inv_determinant;
+    if (t < ray.min || t > ray.max) return false;
+    *t_out = t;
+    return true;
+}
+
+// Point, uv and normal of a triangle hit: triangle/mod.rs:159-164 with
+// get_barycentric_coords :91-114, get_uv :116-120, get_normal :122-126.
+PT_HD void triangle_finish(const LeafTri& tri, const ShadeTri& sh, const Ray& ray, float t, Hit* h) {
+    V3 p0 = ld3(tri.v0), p1 = ld3(tri.v1), p2 = ld3(tri.v2);
+    V3 point = ray.source + ray.direction * t;
+    V3 tn = ld3(sh.true_normal);
+    V3 to0 = p0 - point, to1 = p1 - point, to2 = p2 - point;
+    float b0 = abs_f(dot(cross(to1, to2), tn));
+    float b1 = abs_f(dot(cross(to0, to2), tn));
+    float b2 = abs_f(dot(cross(to0, to1), tn));
+    float sum = b0 + b1 + b2;
+    float c0 = b0 / sum, c1 = b1 / sum, c2 = b2 / sum;
+    h->point = point;
+    h->uv = mk2(sh.uv0[0], sh.uv0[1]) * c0 + mk2(sh.uv1[0], sh.uv1[1]) * c1 + mk2(sh.uv2[0], sh.uv2[1]) * c2;
+    h->normal = ld3(sh.n0) * c0 + ld3(sh.n1) * c1 + ld3(sh.n2) * c2;
+}
+
+// ------------------------------------------------------------------ sphere / plane
+// sphere.rs:59-101
+PT_HD void sphere_trace(const DNode& n, uint32_t node_index, const Ray& ray, Hit* out) {
+    out->hit = 0u;
+    out->hit_inside = 0u;
+    out->t = 0.0f;
+    V3 a = n.center - ray.source;
+    float half_second_k = -dot(a, ray.direction);
+    float discriminant = 4.0f * (half_second_k * half_second_k - (dot(a, a) - n.radius_sqr));
+    if (discriminant < 0.0f) return;
+    float d_sqrt = sqrt_rn(discriminant);
+    float t1 = -half_second_k + d_sqrt / 2.0f;
+    float t2 = -half_second_k - d_sqrt / 2.0f;
+    float t;
+    uint32_t inside = 0u;
+    if (t2 >= ray.min && t2 <= ray.max) {
+        t = t2;
+    } else if (t1 >= ray.min && t1 <= ray.max) {
+        t = t1;
+        inside = 1u;
+    } else {
+        return;
+    }
+    V3 point = t * ray.direction + ray.source;
+    float normal_facing_outside = inside ? -1.0f : 1.0f;
+    V3 normal = (point - n.center) / (n.radius * normal_facing_outside);
+    float u = ptm::atan2_f32(normal.x, normal.z) / (2.0f * kPi) + 0.5f;
+    float v = ptm::asin_f32(normal.y) / kPi + 0.5f;
+    out->hit = 1u;
+    out->hit_inside = inside;
+    out->t = t;
+    out->point = point;
+    out->normal = normal;
+    out->uv = mk2(u, v);
+    out->material_id = n.material_id;
+    out->node_index = node_index;
+    out->tri_index = 0xFFFFFFFFu;
+}
+
+// plane.rs:72-103
+PT_HD void plane_trace(const DNode& n, uint32_t node_index, const Ray& ray, Hit* out) {
+    out->hit = 0u;
+    out->hit_inside = 0u;
+    out->t = 0.0f;
+    float t = dot(n.normal, n.point - ray.source) / dot(n.normal, ray.direction);
+    if (t < ray.min || t > ray.max) return;
+    V3 point = ray.source + ray.direction * t;
+    float normal_facing_dir = -signum_f(dot(ray.direction, n.normal));
+    V3 uv = point - n.point;
+    out->hit = 1u;
+    out->hit_inside = normal_facing_dir < 0.0f ? 1u : 0u;
+    out->t = t;
+    out->point = point;
+    out->normal = n.normal * normal_facing_dir;
+    out->uv = mk2(dot(uv, n.bitangent), dot(uv, n.tangent));
+    out->material_id = n.material_id;
+    out->node_index = node_index;
+    out->tri_index = 0xFFFFFFFFu;
+}
+
+// ray.rs:21-37, with normal_matrix() of the inverse precomputed.
+PT_HD Ray apply_transform(const Ray& r, const M4& inv, const M3& inv_normal) {
+    V3 min_point = r.min * r.direction + r.source;
+    V3 max_point = r.max * r.direction + r.source;
+    V3 s = mul_point(inv, r.source);
+    V3 mn = mul_point(inv, min_point);
+    V3 mx = mul_point(inv, max_point);
+    Ray o;
+    o.source = s;
+    o.direction = mul(inv_normal, r.direction);
+    o.min = length(mn - s);
+    o.max = length(mx - s);
+    return o;
+}
+
+#if defined(__HIPCC__)
+// ------------------------------------------------------------------ BVH traversal
+// The search must return what the linear scan of mesh/mod.rs:57-62 returns: the
+// smallest t, the lowest triangle index among equal t.  Boxes are padded at
+// build time and the slab test is widened, so a subtree is skipped only when no
+// triangle inside it can report a hit at t <= the best so far.
+
+constexpr int kLdsStack = 12;  // entries per lane kept in LDS
+constexpr int kPrivStack = 52; // further entries in private memory
+
+struct TravStack {
+    int32_t* lds;      // this lane's column: lds[k * stride]
+    int stride;
+    int32_t priv[kPrivStack];
+    int sp;
+    __device__ __forceinline__ void push(int32_t v) {
+        if (sp < kLdsStack) lds[sp * stride] = v;
+        else if (sp < kLdsStack + kPrivStack) priv[sp - kLdsStack] = v;
+        sp++;
+    }
+    __device__ __forceinline__ int32_t pop() {
+        if (sp == 0) return kBvhSentinel;
+        sp--;
+        return sp < kLdsStack ? lds[sp * stride] : priv[sp - kLdsStack];
+    }
+};
+
+// Entry distance of the ray into a padded box, or +inf when it misses on
+// [0, limit].  NaN slab terms (0 * inf) do not constrain.
+__device__ __forceinline__ float box_entry(const float* bmin, const float* bmax, V3 o, V3 inv, float limit) {
+    float t0 = 0.0f, t1 = limit;
+    {
+        float ta = (bmin[0] - o.x) * inv.x, tb = (bmax[0] - o.x) * inv.x;
+        float lo = fminf(ta, tb), hi = fmaxf(ta, tb);
+        bool ok = (ta == ta) && (tb == tb);
+        lo = ok ? lo - abs_f(lo) * 4e-7f : 0.0f;
+        hi = ok ? hi + abs_f(hi) * 4e-7f : limit;
+        t0 = fmaxf(t0, lo);
+        t1 = fminf(t1, hi);
+    }
+    {
+        float ta = (bmin[1] - o.y) * inv.y, tb = (bmax[1] - o.y) * inv.y;
+        float lo = fminf(ta, tb), hi = fmaxf(ta, tb);
+        bool ok = (ta == ta) && (tb == tb);
+        lo = ok ? lo - abs_f(lo) * 4e-7f : 0.0f;
+        hi = ok ? hi + abs_f(hi) * 4e-7f : limit;
+        t0 = fmaxf(t0, lo);
+        t1 = fminf(t1, hi);
+    }
+    {
+        float ta = (bmin[2] - o.z) * inv.z, tb = (bmax[2] - o.z) * inv.z;
+        float lo = fminf(ta, tb), hi = fmaxf(ta, tb);
+        bool ok = (ta == ta) && (tb == tb);
+        lo = ok ? lo - abs_f(lo) * 4e-7f : 0.0f;
+        hi = ok ? hi + abs_f(hi) * 4e-7f : limit;
+        t0 = fmaxf(t0, lo);
+        t1 = fminf(t1, hi);
+    }
+    return (t0 <= t1) ? t0 : f32_inf();
+}
+
+__device__ __forceinline__ LeafTri load_tri(const LeafTri* p) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    float4 a = q[0], b = q[1], c = q[2];
+    LeafTri t;
+    t.v0[0] = a.x; t.v0[1] = a.y; t.v0[2] = a.z; t.orig_index = __float_as_uint(a.w);
+    t.v1[0] = b.x; t.v1[1] = b.y; t.v1[2] = b.z; t.pad1 = 0;
+    t.v2[0] = c.x; t.v2[1] = c.y; t.v2[2] = c.z; t.pad2 = 0;
+    return t;
+}
+
+// Closest triangle of `mesh` for `ray` (object space).  best_t starts at +inf;
+// on return *slot is the leaf-order (or, brute force, original-order) position
+// of the winning triangle, *orig its original index.
+__device__ __forceinline__ bool mesh_closest_bvh(const DMesh& mesh, const Ray& ray, TravStack& st, float* best_t,
+                                                 uint32_t* slot, uint32_t* orig) {
+    V3 inv = mk3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
+    float tbest = f32_inf();
+    uint32_t best_orig = 0xFFFFFFFFu, best_slot = 0u;
+    bool found = false;
+    float ray_limit = (ray.max == ray.max) ? ray.max : f32_inf();
+    if (box_entry(mesh.bmin, mesh.bmax, ray.source, inv, ray_limit) == f32_inf()) return false;
+    st.sp = 0;
+    int32_t cur = mesh.root_ref;
+    while (cur != kBvhSentinel) {
+        while (cur >= 0 && cur != kBvhSentinel) {
+            const float4* q = reinterpret_cast<const float4*>(mesh.nodes + cur);
+            float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
+            float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
+            float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
+            int32_t left = __float_as_int(n3.x), right = __float_as_int(n3.y);
+            float limit = fminf(tbest, ray_limit);
+            float tl = box_entry(lmin, lmax, ray.source, inv, limit);
+            float tr = box_entry(rmin, rmax, ray.source, inv, limit);
+            bool hl = tl != f32_inf(), hr = tr != f32_inf();
+            if (hl && hr) {
+                bool left_first = tl <= tr;
+                int32_t nearc = left_first ? left : right;
+                int32_t farc = left_first ? right : left;
+                st.push(farc);
+                cur = nearc;
+            } else if (hl) {
+                cur = left;
+            } else if (hr) {
+                cur = right;
+            } else {
+                cur = st.pop();
+            }
+        }
+        if (cur == kBvhSentinel) break;
+        {
+            uint32_t ref = (uint32_t)(~cur);
+            uint32_t first = ref >> 3, count = (ref & 7u) + 1u;
+            for (uint32_t k = 0; k < count; k++) {
+                LeafTri tri = load_tri(mesh.tris + first + k);
+                float t;
+                if (triangle_hit(ld3(tri.v0), ld3(tri.v1), ld3(tri.v2), ray, &t)) {
+                    if (t < tbest || (found && t == tbest && tri.orig_index < best_orig)) {
+                        tbest = t;
+                        best_orig = tri.orig_index;
+                        best_slot = first + k;
+                        found = true;
+                    }
+                }
+            }
+            cur = st.pop();
+        }
+    }
+    *best_t = tbest;
+    *slot = best_slot;
+    *orig = best_orig;
+    return found;
+}
+
+// mesh/mod.rs:53-65 literally: every triangle, strict <, first wins.
+__device__ __forceinline__ bool mesh_closest_linear(const DMesh& mesh, const Ray& ray, float* best_t, uint32_t* slot,
+                                                    uint32_t* orig) {
+    float tbest = f32_inf();
+    uint32_t best = 0u;
+    bool found = false;
+    for (uint32_t i = 0; i < mesh.tri_count; i++) {
+        LeafTri tri = load_tri(mesh.tris_orig + i);
+        float t;
+        if (triangle_hit(ld3(tri.v0), ld3(tri.v1), ld3(tri.v2), ray, &t) && t < tbest) {
+            tbest = t;
+            best = i;
+            found = true;
+        }
+    }
+    *best_t = tbest;
+    *slot = best;
+    *orig = best;
+    return found;
+}
+
+// hierarchy/mesh.rs:61-66 + mesh/mod.rs:53-65
+__device__ __forceinline__ void mesh_trace(const DScene& sc, const DNode& n, uint32_t node_index, const Ray& ray,
+                                           bool brute, TravStack& st, Hit* out) {
+    const DMesh& mesh = sc.meshes[n.mesh_id];
+    float t;
+    uint32_t slot, orig;
+    bool found = brute ? mesh_closest_linear(mesh, ray, &t, &slot, &orig)
+                       : mesh_closest_bvh(mesh, ray, st, &t, &slot, &orig);
+    out->hit = found ? 1u : 0u;
+    out->hit_inside = 0u;
+    out->t = found ? t : f32_inf(); // the reference returns its running t = +inf on a miss
+    out->material_id = n.material_id;
+    out->node_index = node_index;
+    out->tri_index = found ? orig : 0xFFFFFFFFu;
+    if (found) {
+        LeafTri tri = load_tri((brute ? mesh.tris_orig : mesh.tris) + slot);
+        ShadeTri sh = mesh.shade[orig];
+        triangle_finish(tri, sh, ray, t, out);
+    }
+}
+
+// ------------------------------------------------------------------ scene graph
+// Evaluates scene.hierarchy.trace_ray(ray) over the pre-order node array without
+// recursion.  Semantics per node type:
+//   collection (node_collection.rs:43-55): running best starts at t = +inf, a
+//     child replaces it when child.hit && child.t < best.t;
+//   transform (transform.rs:45-66): child sees apply_transform(ray, M^-1); a hit
+//     comes back as point = M*point', t = |point - ray.source|, normal = N*normal';
+//   kd_tree: its child.
+__device__ __forceinline__ void scene_trace(const DScene& sc, Ray ray, bool brute, TravStack& st, Hit* result) {
+    // Saved state of the open internal nodes, indexed by nesting depth.  Every
+    // lane of a wave walks the same node sequence, so depth and node index are
+    // wave-uniform; only rays and hits differ per lane.
+    Ray saved_ray[kMaxGraphDepth];
+    Hit saved_best[kMaxGraphDepth];
+    Hit best;
+    best.hit = 0u;
+    best.hit_inside = 0u;
+    best.t = f32_inf();
+    best.material_id = 0u;
+    best.node_index = 0xFFFFFFFFu;
+    best.tri_index = 0xFFFFFFFFu;
+    best.point = mk3(0, 0, 0);
+    best.normal = mk3(0, 0, 0);
+    best.uv = mk2(0, 0);
+    Hit cur = best;
+    cur.t = 0.0f;
+    uint32_t i = 0;
+    uint32_t open = 0xFFFFFFFFu; // innermost open collection / transform
+    int depth = 0;
+    const uint32_t n = sc.node_count;
+    for (;;) {
+        while (open != 0xFFFFFFFFu && i == sc.nodes[open].end) {
+            const DNode& on = sc.nodes[open];
+            depth--;
+            if (on.type == 0u) {
+                cur = best;
+                if (depth > 0) best = saved_best[depth];
+            } else {
+                ray = saved_ray[depth];
+                if (cur.hit) {
+                    V3 point = mul_point(on.matrix, cur.point);
+                    cur.t = length(point - ray.source);
+                    cur.point = point;
+                    cur.normal = mul(on.normal_matrix, cur.normal);
+                }
+            }
+            open = on.parent;
+            if (open != 0xFFFFFFFFu && sc.nodes[open].type == 0u && cur.hit && cur.t < best.t) best = cur;
+        }
+        if (i >= n) break;
+        const DNode& nd = sc.nodes[i];
+        uint32_t type = nd.type;
+        if (type == 0u) { // collection
+            if (depth > 0) saved_best[depth] = best;
+            depth++;
+            open = i;
+            best.hit = 0u;
+            best.hit_inside = 0u;
+            best.t = f32_inf();
+            i++;
+            continue;
+        }
+        if (type == 1u) { // transform
+            saved_ray[depth] = ray;
+            depth++;
+            open = i;
+            ray = apply_transform(ray, nd.matrix_inverse, nd.inverse_normal_matrix);
+            i++;
+            continue;
+        }
+        if (type == 5u) { // kd_tree
+            i++;
+            continue;
+        }
+        if (type == 2u) mesh_trace(sc, nd, i, ray, brute, st, &cur);
+        else if (type == 3u) sphere_trace(nd, i, ray, &cur);
+        else plane_trace(nd, i, ray, &cur);
+        i++;
+        if (open != 0xFFFFFFFFu && sc.nodes[open].type == 0u && cur.hit && cur.t < best.t) best = cur;
+    }
+    *result = cur;
+}
+
+// ------------------------------------------------------------------ materials
+// material_input/mod.rs:49-56, texture.rs:53-66, image.rs:39-46
+__device__ __forceinline__ V3 sample_color(const DMaterial& m, V2 uv) {
+    if (!m.color_is_texture) return m.color;
+    if (m.uv_mode == 0u) uv = mk2(clamp_f(uv.x, 0.0f, 1.0f), clamp_f(uv.y, 0.0f, 1.0f));
+    else uv = mk2(uv.x - floorf(uv.x), uv.y - floorf(uv.y));
+    uv.y = 1.0f - uv.y;
+    V2 coords = uv * mk2((float)(m.tex_w - 1u), (float)(m.tex_h - 1u));
+    uint32_t x = f32_as_u32(coords.x), y = f32_as_u32(coords.y);
+    if (x >= m.tex_w) x = m.tex_w - 1u;
+    if (y >= m.tex_h) y = m.tex_h - 1u;
+    uint32_t texel = reinterpret_cast<const uint32_t*>(m.texels)[(size_t)y * m.tex_w + x];
+    return mk3((float)(texel & 0xFFu) / 256.0f, (float)((texel >> 8) & 0xFFu) / 256.0f,
+               (float)((texel >> 16) & 0xFFu) / 256.0f);
+}
+
+// math/src/lib.rs:272-280
+__device__ __forceinline__ V3 random_on_unit_sphere(float rand_0, float rand_1) {
+    float theta = rand_0 * kPi * 2.0f;
+    float phi = ptm::acos_f32((2.0f * rand_1) - 1.0f);
+    float sp = ptm::sin_f32(phi), cp = ptm::cos_f32(phi);
+    float x = sp * ptm::cos_f32(theta);
+    float y = sp * ptm::sin_f32(theta);
+    return mk3(x, y, cp);
+}
+
+// base.rs:51-63
+__device__ __forceinline__ float fresnel_reflection(float theta_cos, float refraction) {
+    float refr_sqr = refraction * refraction;
+    float c = theta_cos * refraction;
+    float g = sqrt_rn(1.0f + c * c - refr_sqr);
+    float a = (g - c) / (g + c);
+    float b_nom = c * (g + c) - refr_sqr;
+    float b_den = c * (g - c) + refr_sqr;
+    float b = b_nom / b_den;
+    return 0.5f * a * a * (1.0f + b * b);
+}
+
+__device__ __forceinline__ float powi5(float x) {
+    float x2 = x * x;
+    float x4 = x2 * x2;
+    return x * x4;
+}
+
+// Material::get_color.  Returns true for GetColorResult::Color (value in *a),
+// false for NextRayColorMultiplierAndDirection (*a multiplier, *dir direction).
+__device__ __forceinline__ bool material_get_color(const DMaterial& m, V3 dir, const Hit& tr, Rng& rng, V3* a,
+                                                   V3* out_dir) {
+    if (m.type == 0u) { // base.rs:87-145
+        float random_num = rng.gen_range(0.0f, 1.0f);
+        if (random_num < m.reflective) {
+            *a = splat3(1.0f);
+            *out_dir = reflect(dir, tr.normal);
+            return false;
+        } else if (random_num < m.reflective + m.emissive) {
+            *a = m.emission;
+            return true;
+        } else if (random_num < m.reflective + m.emissive + m.refractive) {
+            float cosv = dot(mk3(0, 0, 0) - dir, tr.normal);
+            float refraction = tr.hit_inside ? m.refraction : 1.0f / m.refraction;
+            float fresnel = fresnel_reflection(cosv, refraction);
+            float rnd = rng.gen_range(0.0f, 1.0f);
+            V3 new_dir;
+            if (rnd < fresnel) {
+                new_dir = reflect(dir, tr.normal);
+            } else {
+                // lib.rs:263-270
+                float d = dot(tr.normal, dir);
+                float k = 1.0f - refraction * refraction * (1.0f - d * d);
+                if (k < 0.0f) {
+                    V3 reflected = reflect(dir, tr.normal);
+                    new_dir = reflected * (tr.hit_inside ? -1.0f : 1.0f);
+                } else {
+                    new_dir = refraction * dir - tr.normal * (refraction * d + sqrt_rn(k));
+                }
+            }
+            *a = splat3(1.0f);
+            *out_dir = new_dir;
+            return false;
+        } else {
+            float r0 = rng.gen_range(0.0f, 1.0f);
+            float r1 = rng.gen_range(0.0f, 1.0f);
+            V3 new_direction = random_on_unit_sphere(r0, r1);
+            if (dot(new_direction, tr.normal) < 0.0f) new_direction = mk3(0, 0, 0) - new_direction;
+            *a = sample_color(m, tr.uv);
+            *out_dir = new_direction;
+            return false;
+        }
+    }
+    // pbr.rs:105-136
+    V3 input_dir = dir * -1.0f;
+    float rand_0 = rng.gen_range(0.0f, 1.0f);
+    float rand_1 = rng.gen_range(0.0f, 1.0f);
+    V3 normal = tr.normal;
+    V3 mulv, output_dir;
+    float selection_probability;
+    if (rng.gen_bool_half()) {
+        // lib.rs:196-212, :291-300
+        float r0 = ptm::cos_f32(kPi * 0.5f * (1.0f - rand_0));
+        float theta = rand_1 * kPi * 2.0f;
+        V3 j = normal;
+        V3 i = (abs_f(j.y) + abs_f(j.z) < kEpsilon) ? mk3(-j.y, j.x, 0.0f) : mk3(0.0f, j.z, -j.y);
+        V3 k = cross(j, i);
+        float r = sqrt_rn(r0);
+        V3 rnd = j * (1.0f - r0 + kEpsilon);
+        output_dir = rnd + r * (i * ptm::cos_f32(theta) + k * ptm::sin_f32(theta));
+        selection_probability = dot(output_dir, normal);
+        // brdf_diffuse, pbr.rs:64-73
+        V3 h = normalized(output_dir + input_dir);
+        V3 specular_k = m.f0 + (splat3(1.0f) - m.f0) * powi5(1.0f - dot(h, input_dir));
+        V3 diffuse_k = (splat3(1.0f) - specular_k) * (1.0f - m.metallic);
+        V3 diffuse = kInvPi * m.albedo;
+        mulv = diffuse_k * diffuse;
+    } else {
+        // lib.rs:282-289
+        V3 rnd = random_on_unit_sphere(rand_0, rand_1);
+        output_dir = (dot(rnd, normal) < 0.0f) ? rnd * -1.0f : rnd;
+        selection_probability = 1.0f;
+        // brdf_specular, pbr.rs:75-87 with ndf :48-53, geometry :55-58, fresnel :60-62
+        float ni = dot(normal, input_dir);
+        float no = dot(normal, output_dir);
+        V3 h = normalized(output_dir + input_dir);
+        float kk = ((1.0f + m.roughness) * (1.0f + m.roughness)) / 8.0f;
+        float g_i = ni / (ni * (1.0f - kk) + kk);
+        float g_o = no / (no * (1.0f - kk) + kk);
+        float geometry = g_i * g_o;
+        float nh = clamp_f(dot(normal, h), 0.0001f, 0.9999f);
+        float r4 = m.roughness_sqr * m.roughness_sqr;
+        float denom_sqrt = nh * nh * (r4 - 1.0f) + 1.0f;
+        float ndf = r4 / (denom_sqrt * denom_sqrt * kPi);
+        V3 specular_k = m.f0 + (splat3(1.0f) - m.f0) * powi5(1.0f - dot(h, input_dir));
+        float specular = geometry * ndf / (4.0f * ni * no);
+        mulv = specular_k * specular;
+    }
+    mulv = mulv * (dot(output_dir, normal) / selection_probability * kPi * 1.0f);
+    *a = mulv;
+    *out_dir = output_dir;
+    return false;
+}
+#endif // __HIPCC__
+
+} // namespace ptk

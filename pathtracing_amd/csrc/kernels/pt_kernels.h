@@ -1,0 +1,50 @@
+// Host-callable entry points of the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
+
+#include "../../../include/pathtracing_amd.h"
+#include "pt_scene_device.h"
+
+namespace ptk {
+
+// Scratch memory of the wavefront pipeline, owned by the scene handle and grown
+// on demand.  Queue records are three 16-byte rows per path (structure of
+// float4 arrays, so every lane's load is 16 bytes and a wave's is 1 KiB):
+//   a = (source.xyz, ray.min)   b = (direction.xyz, bits(path id))
+//   c = (multiplier.rgb, bits(random-stream draw counter))
+struct Workspace {
+    float4* queue[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    float* contrib = nullptr;    // 3 floats per path of the batch: its final colour
+    uint32_t* counters = nullptr; // kMaxDepthCounters queue lengths
+    uint64_t capacity_paths = 0;
+    uint64_t* ray_total = nullptr; // device-side running sum of traced rays
+};
+constexpr uint32_t kMaxDepthCounters = 4096;
+
+struct BatchGeometry {
+    uint32_t x0, y0, w, h; // pixel rectangle, camera space
+    uint32_t nbx, nby;     // 8x8 pixel blocks covering it
+    uint32_t npp;          // path slots per sample = nbx * nby * 64
+};
+
+// Runs samples [sample_first, sample_first + sample_count) of every pixel of the
+// rectangle and adds their colours, in sample order, into d_accum (camera-space
+// layout, (x + y*W)*3).
+hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeometry& geo, uint64_t seed,
+                        uint64_t sample_first, uint32_t sample_count, uint32_t trace_depth, bool brute,
+                        Workspace& ws, float* d_accum, hipStream_t stream);
+
+hipError_t resolve_image(const float* d_accum, uint32_t width, uint32_t height, float scale, float* d_out,
+                         hipStream_t stream);
+
+hipError_t trace_closest(const DScene& scene, const PtRay* d_rays, size_t n, bool brute, PtHit* d_hits,
+                         hipStream_t stream);
+
+hipError_t generate_rays(const DCamera& cam, uint64_t seed, const uint32_t* d_pixel_xy, const uint64_t* d_sample,
+                         size_t n, PtRay* d_rays, hipStream_t stream);
+
+hipError_t shade(const DScene& scene, const PtVec3* d_dirs, const PtHit* d_hits, const uint64_t* d_stream,
+                 uint64_t seed, size_t n, uint32_t* d_kind, PtVec3* d_a, PtVec3* d_dir, hipStream_t stream);
+
+} // namespace ptk

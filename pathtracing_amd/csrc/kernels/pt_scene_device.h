@@ -1,0 +1,121 @@
+// Device-resident scene layout (plain structs, uploaded once per scene).
+#pragma once
+#include "pt_vec.h"
+
+namespace ptk {
+
+// ---- acceleration structure of one mesh --------------------------------------
+// 64-byte node = one cache-line-half fetch brings both children's boxes.  A child
+// reference >= 0 is another node; < 0 is a leaf: ~ref = (first_triangle << 3) |
+// (count - 1), count in 1..8, triangles addressed in leaf order.
+struct alignas(64) BvhNode {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    int32_t left, right;
+    int32_t pad[2];
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
+constexpr int32_t kBvhSentinel = 0x7FFFFFFF; // "stack empty"
+constexpr int kLeafMaxTris = 8;
+constexpr int kBvhMaxDepth = 60; // builder guarantee; traversal stack holds 64
+
+PT_HD int32_t bvh_make_leaf(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
+
+// Triangle as the intersection loop reads it: three 16-byte rows
+//   (v0.xyz, bits of original index) (v1.xyz, 0) (v2.xyz, 0)
+struct alignas(16) LeafTri {
+    float v0[3];
+    uint32_t orig_index;
+    float v1[3];
+    uint32_t pad1;
+    float v2[3];
+    uint32_t pad2;
+};
+static_assert(sizeof(LeafTri) == 48, "LeafTri must be 48 bytes");
+
+// Everything Triangle::trace_ray needs after the hit is known
+// (triangle/mod.rs:90-127), indexed by the ORIGINAL triangle index.
+struct alignas(16) ShadeTri {
+    float true_normal[3];
+    float n0[3], n1[3], n2[3];
+    float uv0[2], uv1[2], uv2[2];
+    float pad[2];
+};
+static_assert(sizeof(ShadeTri) == 80, "ShadeTri must be 80 bytes");
+
+struct DMesh {
+    const BvhNode* nodes;   // node 0 is the root (absent when root_ref is a leaf)
+    const LeafTri* tris;    // leaf order
+    const LeafTri* tris_orig; // original order (brute-force scan)
+    const ShadeTri* shade;  // original order
+    uint32_t tri_count;
+    uint32_t node_count;
+    int32_t root_ref;       // node 0, or a leaf reference for tiny meshes
+    uint32_t pad;
+    float bmin[3], bmax[3]; // padded bounds of the whole mesh (object space)
+};
+
+// ---- scene graph ------------------------------------------------------------
+// Pre-order array; `end` = index one past the node's subtree.
+struct DNode {
+    uint32_t type;
+    uint32_t end;
+    uint32_t material_id;
+    uint32_t mesh_id;
+    uint32_t parent;  // nearest enclosing collection / transform node, or 0xFFFFFFFF
+    uint32_t depth;   // number of enclosing collection / transform nodes
+    // TRANSFORM (transform.rs:33-40 plus the per-ray normal_matrix() of ray.rs:29)
+    M4 matrix, matrix_inverse;
+    M3 normal_matrix, inverse_normal_matrix;
+    // SPHERE (sphere.rs:48-53)
+    V3 center;
+    float radius, radius_sqr;
+    // PLANE (plane.rs:60-66), axes normalised
+    V3 point, normal, tangent, bitangent;
+};
+
+struct DMaterial {
+    uint32_t type;
+    uint32_t color_is_texture;
+    uint32_t uv_mode;
+    uint32_t tex_w, tex_h;
+    const uint8_t* texels; // RGBA8, top row first
+    V3 color, emission;
+    float refraction, reflective, emissive, refractive;
+    V3 albedo;
+    float roughness, metallic;
+    V3 f0;               // pbr.rs:93
+    float roughness_sqr; // pbr.rs:94
+};
+
+struct DScene {
+    const DNode* nodes;
+    uint32_t node_count;
+    const DMesh* meshes;
+    const DMaterial* materials;
+    uint32_t mesh_count, material_count;
+};
+
+constexpr int kMaxGraphDepth = 8; // nested collection/transform frames the kernels keep
+
+// Camera::get_ray inputs with the per-task constants precomputed on the host.
+struct DCamera {
+    float res_x, res_y;      // resolution as f32
+    uint32_t width, height;
+    M3 rotation;
+    V3 position;
+    float focal_length, near_plane, bokeh_size;
+    float viewport_x, viewport_y; // camera.rs:56-57
+    uint32_t bokeh_shape;
+};
+
+// One record of the hit the tracer reports (RayTraceResult + bookkeeping).
+struct Hit {
+    float t;
+    uint32_t hit, hit_inside, node_index, tri_index, material_id;
+    V3 point, normal;
+    V2 uv;
+};
+
+} // namespace ptk

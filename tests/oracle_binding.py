@@ -1,0 +1,150 @@
+"""ctypes binding of the CPU oracle (``oracle/pt_oracle.cpp``).
+
+Test infrastructure: imported by tests, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` only — never by the package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from pathtracing_amd import _native as N
+from pathtracing_amd.renderer import HIT_DTYPE
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "build", "libpt_oracle.so")
+
+ACCEL_LINEAR, ACCEL_BVH = 0, 1
+MATH_LIBM, MATH_PORTABLE = 0, 1
+
+
+class OracleStats(C.Structure):
+    _fields_ = [
+        ("rays", C.c_uint64),
+        ("box_tests", C.c_uint64),
+        ("tri_tests", C.c_uint64),
+        ("hits", C.c_uint64),
+        ("tex_fetches", C.c_uint64),
+        ("paths", C.c_uint64),
+        ("seconds", C.c_double),
+    ]
+
+
+class Oracle:
+    def __init__(self, lib: C.CDLL):
+        self.lib = lib
+        V = C.c_void_p
+        lib.oracle_last_error.restype = C.c_char_p
+        lib.oracle_scene_create.restype = C.c_int
+        lib.oracle_scene_create.argtypes = [C.POINTER(N.PtSceneDesc), C.POINTER(V)]
+        lib.oracle_scene_destroy.argtypes = [V]
+        lib.oracle_trace.restype = C.c_int
+        lib.oracle_trace.argtypes = [V, V, C.c_size_t, C.c_int, C.c_int, C.c_int, V, C.POINTER(OracleStats)]
+        lib.oracle_generate_rays.restype = C.c_int
+        lib.oracle_generate_rays.argtypes = [C.POINTER(N.PtCamera), C.c_uint64, V, V, C.c_size_t, C.c_int, V]
+        lib.oracle_shade.restype = C.c_int
+        lib.oracle_shade.argtypes = [V, V, V, V, C.c_uint64, C.c_size_t, C.c_int, V, V, V]
+        lib.oracle_render.restype = C.c_int
+        lib.oracle_render.argtypes = [V, C.POINTER(N.PtRenderTask), C.POINTER(N.PtRenderOpts), C.c_int, C.c_int, C.c_int,
+                                      V, C.POINTER(OracleStats)]
+        lib.oracle_rng_u32.restype = C.c_uint32
+        lib.oracle_rng_u32.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+        lib.oracle_rng_range.restype = C.c_float
+        lib.oracle_rng_range.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_float, C.c_float]
+        lib.oracle_portable_math_array.argtypes = [C.c_int, V, V, C.c_size_t, V]
+        lib.oracle_transform_matrices.argtypes = [C.POINTER(N.PtMat4), V, V, V]
+
+    def error(self) -> str:
+        return self.lib.oracle_last_error().decode()
+
+    def scene(self, desc_pointer) -> "OracleScene":
+        h = C.c_void_p()
+        rc = self.lib.oracle_scene_create(desc_pointer, C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"oracle_scene_create failed ({rc}): {self.error()}")
+        return OracleScene(self, h)
+
+    def generate_rays(self, camera, seed, pixel_xy, sample_index, math=MATH_LIBM) -> np.ndarray:
+        cam = camera.to_native()
+        pixel_xy = np.ascontiguousarray(pixel_xy, dtype=np.uint32)
+        sample_index = np.ascontiguousarray(sample_index, dtype=np.uint64)
+        n = sample_index.shape[0]
+        rays = np.zeros((n, 8), dtype=np.float32)
+        rc = self.lib.oracle_generate_rays(C.byref(cam), seed, pixel_xy.ctypes.data, sample_index.ctypes.data, n, math,
+                                           rays.ctypes.data)
+        assert rc == 0
+        return rays
+
+    def portable_math(self, fn: int, x: np.ndarray, y=None) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.zeros_like(x)
+        yp = None
+        if y is not None:
+            y = np.ascontiguousarray(y, dtype=np.float32)
+            yp = y.ctypes.data
+        self.lib.oracle_portable_math_array(fn, x.ctypes.data, yp, x.size, out.ctypes.data)
+        return out
+
+
+class OracleScene:
+    def __init__(self, oracle: Oracle, handle):
+        self.o = oracle
+        self.h = handle
+
+    def trace(self, rays: np.ndarray, accel=ACCEL_LINEAR, math=MATH_LIBM, threads=0, want_stats=False):
+        rays = np.ascontiguousarray(rays, dtype=np.float32)
+        hits = np.zeros(rays.shape[0], dtype=HIT_DTYPE)
+        st = OracleStats()
+        rc = self.o.lib.oracle_trace(self.h, rays.ctypes.data, rays.shape[0], accel, math, threads, hits.ctypes.data,
+                                     C.byref(st))
+        assert rc == 0
+        return (hits, st) if want_stats else hits
+
+    def shade(self, directions, hits, stream_ids, seed=0, math=MATH_LIBM):
+        directions = np.ascontiguousarray(directions, dtype=np.float32)
+        hits = np.ascontiguousarray(hits)
+        stream_ids = np.ascontiguousarray(stream_ids, dtype=np.uint64)
+        n = directions.shape[0]
+        kind = np.zeros(n, dtype=np.uint32)
+        a = np.zeros((n, 3), dtype=np.float32)
+        d = np.zeros((n, 3), dtype=np.float32)
+        rc = self.o.lib.oracle_shade(self.h, directions.ctypes.data, hits.ctypes.data, stream_ids.ctypes.data, seed, n,
+                                     math, kind.ctypes.data, a.ctypes.data, d.ctypes.data)
+        assert rc == 0
+        return kind, a, d
+
+    def render(self, task, opts=None, accel=ACCEL_LINEAR, math=MATH_LIBM, threads=0):
+        t = task.to_native()
+        w, h = int(t.camera.resolution_x), int(t.camera.resolution_y)
+        out = np.zeros((h, w, 3), dtype=np.float32)
+        st = OracleStats()
+        o = opts.to_native() if opts is not None else None
+        rc = self.o.lib.oracle_render(self.h, C.byref(t), C.byref(o) if o is not None else None, accel, math, threads,
+                                      out.ctypes.data, C.byref(st))
+        if rc != 0:
+            raise RuntimeError(f"oracle_render failed ({rc})")
+        return out, st
+
+    def close(self):
+        if self.h:
+            self.o.lib.oracle_scene_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def build() -> None:
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+
+
+def load() -> Oracle:
+    if not os.path.exists(LIB):
+        build()
+    return Oracle(C.CDLL(LIB))
