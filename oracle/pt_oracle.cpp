@@ -590,6 +590,12 @@ Result mesh_trace_bvh(const Mesh& mesh, const Ray& ray, Stats* st) {
     Result result;
     result.t = F32_INF;
     if (mesh.bvh.nodes.empty()) return result;
+    // Non-finite rays miss every triangle (u comes out infinite or NaN in
+    // triangle_trace), and NaN must not cull in the slab test: answer directly
+    // instead of walking the whole tree.
+    if (!std::isfinite(ray.source.x) || !std::isfinite(ray.source.y) || !std::isfinite(ray.source.z) ||
+        !std::isfinite(ray.direction.x) || !std::isfinite(ray.direction.y) || !std::isfinite(ray.direction.z))
+        return result;
     float inv[3] = {1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z};
     int stack[128];
     int sp = 0;

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libpathtracing_amd.so")
 PT_OK = 0
 PT_NO_INDEX = 0xFFFFFFFF
 PT_FLAG_BRUTE_FORCE = 1
+PT_FLAG_PROFILE = 2
 
 NODE_COLLECTION, NODE_TRANSFORM, NODE_MESH, NODE_SPHERE, NODE_PLANE, NODE_KD_TREE = range(6)
 MATERIAL_BASE, MATERIAL_PBR = 0, 1
@@ -152,7 +153,14 @@ class PtRenderOpts(C.Structure):
 
 
 class PtRenderStats(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("render_ms", C.c_double), ("bvh_bytes", C.c_uint64)]
+    _fields_ = [
+        ("rays", C.c_uint64),
+        ("paths", C.c_uint64),
+        ("render_ms", C.c_double),
+        ("bvh_bytes", C.c_uint64),
+        ("segment_kernel_ms", C.c_double),
+        ("segment_kernel_launches", C.c_uint64),
+    ]
 
 
 class PtHit(C.Structure):
@@ -202,12 +210,32 @@ class PathTracingError(RuntimeError):
         self.message = message
 
 
+def _preload_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch wheels bundle their own copy of
+    libamdhip64 (same soname as the system one); if this library pulled in the
+    system copy and torch later loaded its own, the second runtime would find no
+    device.  Loading torch's copy first, by path, makes both resolve to it.
+    Without torch installed the system runtime is used."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def _load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C pathtracing_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path."
         )
+    _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError here = header and library disagree

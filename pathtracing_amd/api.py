@@ -103,12 +103,13 @@ class RenderOpts:
     brute_force: bool = False
     tile: Optional[tuple] = None  # (x0, y0, w, h) in camera space
     paths_per_batch: int = 0
+    profile: bool = False  # time each path-segment kernel launch (RenderStats.segment_kernel_ms)
 
     def to_native(self) -> N.PtRenderOpts:
         o = N.PtRenderOpts()
         o.seed = self.seed
         o.sample_offset = self.sample_offset
-        o.flags = N.PT_FLAG_BRUTE_FORCE if self.brute_force else 0
+        o.flags = (N.PT_FLAG_BRUTE_FORCE if self.brute_force else 0) | (N.PT_FLAG_PROFILE if self.profile else 0)
         if self.tile is not None:
             o.tile_x0, o.tile_y0, o.tile_w, o.tile_h = (int(v) for v in self.tile)
         o.paths_per_batch = self.paths_per_batch

@@ -91,7 +91,19 @@ struct PtScene {
         ws.contrib = nullptr;
         ws.capacity_paths = 0;
     }
+    // Fixed state of the trace kernels: counters and the spill columns of the
+    // persistent grid (4 blocks of 256 threads per compute unit).
+    void ensure_trace_state() {
+        if (ws.spill) return;
+        hipDeviceProp_t prop;
+        hip_check(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
+        uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
+        ws.persistent_blocks = cus * 4u;
+        size_t bytes = (size_t)ws.persistent_blocks * ptk::kTraceBlock * ptk::spill_dwords_per_thread() * sizeof(uint32_t);
+        hip_check(hipMalloc(reinterpret_cast<void**>(&ws.spill), bytes), "hipMalloc spill");
+    }
     void ensure_workspace(uint64_t paths) {
+        ensure_trace_state();
         if (!ws.counters) {
             hip_check(hipMalloc(reinterpret_cast<void**>(&ws.counters), sizeof(uint32_t) * ptk::kMaxDepthCounters),
                       "hipMalloc counters");
@@ -109,6 +121,7 @@ struct PtScene {
         free_workspace();
         if (ws.counters) (void)hipFree(ws.counters);
         if (ws.ray_total) (void)hipFree(ws.ray_total);
+        if (ws.spill) (void)hipFree(ws.spill);
         for (void* p : allocs) (void)hipFree(p);
     }
 };
@@ -331,6 +344,14 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
         hip_check(hipEventRecord(ev0, stream), "hipEventRecord");
     }
     bool brute = (o.flags & PT_FLAG_BRUTE_FORCE) != 0;
+    std::vector<hipEvent_t> seg_events;
+    bool profile = stats && (o.flags & PT_FLAG_PROFILE) != 0;
+    struct EventCleanup {
+        std::vector<hipEvent_t>& v;
+        ~EventCleanup() {
+            for (hipEvent_t e : v) (void)hipEventDestroy(e);
+        }
+    } cleanup{seg_events};
     uint64_t paths = 0;
     for (uint32_t br = 0; br < total_block_rows; br += band_block_rows) {
         ptk::BatchGeometry g;
@@ -344,7 +365,7 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
         for (uint64_t s = 0; s < task->iterations; s += samples_per_batch) {
             uint32_t cnt = (uint32_t)std::min<uint64_t>(samples_per_batch, task->iterations - s);
             hip_check(ptk::render_batch(scene->d, cam, g, o.seed, o.sample_offset + s, cnt, (uint32_t)task->trace_depth,
-                                        brute, scene->ws, d_accum, stream),
+                                        brute, scene->ws, d_accum, stream, profile ? &seg_events : nullptr),
                       "render_batch");
             paths += (uint64_t)cnt * g.w * g.h;
         }
@@ -362,6 +383,14 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
         stats->paths = paths;
         stats->render_ms = ms;
         stats->bvh_bytes = scene->bvh_bytes;
+        stats->segment_kernel_ms = 0.0;
+        stats->segment_kernel_launches = 0;
+        for (size_t i = 0; i + 1 < seg_events.size(); i += 2) {
+            float seg = 0.0f;
+            hip_check(hipEventElapsedTime(&seg, seg_events[i], seg_events[i + 1]), "hipEventElapsedTime");
+            stats->segment_kernel_ms += seg;
+            stats->segment_kernel_launches++;
+        }
     }
 }
 
@@ -521,8 +550,9 @@ PtStatus pt_trace_closest(PtScene* scene, const PtRay* rays, size_t n, uint32_t 
         DeviceGuard guard(scene->device);
         DevBuf d_rays(n * sizeof(PtRay)), d_hits(n * sizeof(PtHit));
         hip_check(hipMemcpy(d_rays.p, rays, n * sizeof(PtRay), hipMemcpyHostToDevice), "hipMemcpy H2D");
+        scene->ensure_trace_state();
         hip_check(ptk::trace_closest(scene->d, static_cast<const PtRay*>(d_rays.p), n, (flags & PT_FLAG_BRUTE_FORCE) != 0,
-                                     static_cast<PtHit*>(d_hits.p), nullptr),
+                                     static_cast<PtHit*>(d_hits.p), scene->ws, nullptr),
                   "trace_closest");
         hip_check(hipMemcpy(out_hits, d_hits.p, n * sizeof(PtHit), hipMemcpyDeviceToHost), "hipMemcpy D2H");
     });

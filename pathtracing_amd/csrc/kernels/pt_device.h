@@ -193,25 +193,93 @@ PT_HD Ray apply_transform(const Ray& r, const M4& inv, const M3& inv_normal) {
 // build time and the slab test is widened, so a subtree is skipped only when no
 // triangle inside it can report a hit at t <= the best so far.
 
-constexpr int kLdsStack = 12;  // entries per lane kept in LDS
-constexpr int kPrivStack = 52; // further entries in private memory
+constexpr int kLdsStack = 16;   // traversal-stack entries per lane kept in LDS
+constexpr int kSpillStack = 48; // further entries in the lane's global spill column
+
+// Per-lane spill column in global memory (the kernels run a fixed, persistent
+// grid, so the area is sized once).  Dword k of lane `tid` lives at
+// base[k * stride + tid]: lanes of a wave touching the same k coalesce.
+// Layout of a column: [0, kSpillStack) traversal-stack overflow, then one
+// 23-dword frame per scene-graph nesting level (saved ray, saved running best).
+constexpr int kFrameDwords = 23;
+constexpr int kSpillDwords = kSpillStack + kMaxGraphDepth * kFrameDwords;
 
 struct TravStack {
-    int32_t* lds;      // this lane's column: lds[k * stride]
+    int32_t* lds; // this lane's column: lds[k * stride]
     int stride;
-    int32_t priv[kPrivStack];
+    uint32_t* spill; // this lane's column: spill[k * spill_stride]
+    uint32_t spill_stride;
     int sp;
     __device__ __forceinline__ void push(int32_t v) {
         if (sp < kLdsStack) lds[sp * stride] = v;
-        else if (sp < kLdsStack + kPrivStack) priv[sp - kLdsStack] = v;
+        else if (sp < kLdsStack + kSpillStack) spill[(size_t)(sp - kLdsStack) * spill_stride] = (uint32_t)v;
         sp++;
     }
     __device__ __forceinline__ int32_t pop() {
         if (sp == 0) return kBvhSentinel;
         sp--;
-        return sp < kLdsStack ? lds[sp * stride] : priv[sp - kLdsStack];
+        return sp < kLdsStack ? lds[sp * stride] : (int32_t)spill[(size_t)(sp - kLdsStack) * spill_stride];
+    }
+    __device__ __forceinline__ uint32_t* frame(int depth) const {
+        return spill + (size_t)(kSpillStack + depth * kFrameDwords) * spill_stride;
     }
 };
+
+__device__ __forceinline__ void spill_store_ray(const TravStack& st, int depth, const Ray& r) {
+    uint32_t* f = st.frame(depth);
+    const size_t s = st.spill_stride;
+    f[0 * s] = __float_as_uint(r.source.x);
+    f[1 * s] = __float_as_uint(r.source.y);
+    f[2 * s] = __float_as_uint(r.source.z);
+    f[3 * s] = __float_as_uint(r.direction.x);
+    f[4 * s] = __float_as_uint(r.direction.y);
+    f[5 * s] = __float_as_uint(r.direction.z);
+    f[6 * s] = __float_as_uint(r.min);
+    f[7 * s] = __float_as_uint(r.max);
+}
+__device__ __forceinline__ Ray spill_load_ray(const TravStack& st, int depth) {
+    const uint32_t* f = st.frame(depth);
+    const size_t s = st.spill_stride;
+    Ray r;
+    r.source = mk3(__uint_as_float(f[0 * s]), __uint_as_float(f[1 * s]), __uint_as_float(f[2 * s]));
+    r.direction = mk3(__uint_as_float(f[3 * s]), __uint_as_float(f[4 * s]), __uint_as_float(f[5 * s]));
+    r.min = __uint_as_float(f[6 * s]);
+    r.max = __uint_as_float(f[7 * s]);
+    return r;
+}
+__device__ __forceinline__ void spill_store_hit(const TravStack& st, int depth, const Hit& h) {
+    uint32_t* f = st.frame(depth) + (size_t)8 * st.spill_stride;
+    const size_t s = st.spill_stride;
+    f[0 * s] = __float_as_uint(h.t);
+    f[1 * s] = h.hit | (h.hit_inside << 1);
+    f[2 * s] = h.node_index;
+    f[3 * s] = h.tri_index;
+    f[4 * s] = h.material_id;
+    f[5 * s] = __float_as_uint(h.point.x);
+    f[6 * s] = __float_as_uint(h.point.y);
+    f[7 * s] = __float_as_uint(h.point.z);
+    f[8 * s] = __float_as_uint(h.normal.x);
+    f[9 * s] = __float_as_uint(h.normal.y);
+    f[10 * s] = __float_as_uint(h.normal.z);
+    f[11 * s] = __float_as_uint(h.uv.x);
+    f[12 * s] = __float_as_uint(h.uv.y);
+}
+__device__ __forceinline__ Hit spill_load_hit(const TravStack& st, int depth) {
+    const uint32_t* f = st.frame(depth) + (size_t)8 * st.spill_stride;
+    const size_t s = st.spill_stride;
+    Hit h;
+    h.t = __uint_as_float(f[0 * s]);
+    uint32_t flags = f[1 * s];
+    h.hit = flags & 1u;
+    h.hit_inside = (flags >> 1) & 1u;
+    h.node_index = f[2 * s];
+    h.tri_index = f[3 * s];
+    h.material_id = f[4 * s];
+    h.point = mk3(__uint_as_float(f[5 * s]), __uint_as_float(f[6 * s]), __uint_as_float(f[7 * s]));
+    h.normal = mk3(__uint_as_float(f[8 * s]), __uint_as_float(f[9 * s]), __uint_as_float(f[10 * s]));
+    h.uv = mk2(__uint_as_float(f[11 * s]), __uint_as_float(f[12 * s]));
+    return h;
+}
 
 // Entry distance of the ray into a padded box, or +inf when it misses on
 // [0, limit].  NaN slab terms (0 * inf) do not constrain.
@@ -257,6 +325,11 @@ __device__ __forceinline__ LeafTri load_tri(const LeafTri* p) {
     return t;
 }
 
+__device__ __forceinline__ bool all_finite(V3 v) {
+    const uint32_t e = 0x7F800000u;
+    return ((__float_as_uint(v.x) & e) != e) && ((__float_as_uint(v.y) & e) != e) && ((__float_as_uint(v.z) & e) != e);
+}
+
 // Closest triangle of `mesh` for `ray` (object space).  best_t starts at +inf;
 // on return *slot is the leaf-order (or, brute force, original-order) position
 // of the winning triangle, *orig its original index.
@@ -266,6 +339,14 @@ __device__ __forceinline__ bool mesh_closest_bvh(const DMesh& mesh, const Ray& r
     float tbest = f32_inf();
     uint32_t best_orig = 0xFFFFFFFFu, best_slot = 0u;
     bool found = false;
+    // A ray with a NaN or infinite origin or direction component cannot hit any
+    // triangle: in triangle_hit the non-finite value reaches u = (tvec.pvec)/det
+    // as an infinity or a NaN and fails 0 <= u <= 1 (the linear scan would test
+    // every triangle and reject every one).  Such rays do occur: the reference's
+    // cosine-weighted sampler takes sqrt(cos(f32 pi/2)) = sqrt(-4.4e-8) when its
+    // random number is exactly 0.  Without this exit the slab test, which must
+    // not cull on NaN, would walk the whole tree.
+    if (!all_finite(ray.source) || !all_finite(ray.direction)) return false;
     float ray_limit = (ray.max == ray.max) ? ray.max : f32_inf();
     if (box_entry(mesh.bmin, mesh.bmax, ray.source, inv, ray_limit) == f32_inf()) return false;
     st.sp = 0;
@@ -371,11 +452,9 @@ __device__ __forceinline__ void mesh_trace(const DScene& sc, const DNode& n, uin
 //     comes back as point = M*point', t = |point - ray.source|, normal = N*normal';
 //   kd_tree: its child.
 __device__ __forceinline__ void scene_trace(const DScene& sc, Ray ray, bool brute, TravStack& st, Hit* result) {
-    // Saved state of the open internal nodes, indexed by nesting depth.  Every
-    // lane of a wave walks the same node sequence, so depth and node index are
-    // wave-uniform; only rays and hits differ per lane.
-    Ray saved_ray[kMaxGraphDepth];
-    Hit saved_best[kMaxGraphDepth];
+    // The saved state of the open internal nodes (outer ray of a transform, running
+    // best of an enclosing collection) lives in the lane's spill column, indexed by
+    // nesting depth.
     Hit best;
     best.hit = 0u;
     best.hit_inside = 0u;
@@ -398,9 +477,9 @@ __device__ __forceinline__ void scene_trace(const DScene& sc, Ray ray, bool brut
             depth--;
             if (on.type == 0u) {
                 cur = best;
-                if (depth > 0) best = saved_best[depth];
+                if (depth > 0) best = spill_load_hit(st, depth);
             } else {
-                ray = saved_ray[depth];
+                ray = spill_load_ray(st, depth);
                 if (cur.hit) {
                     V3 point = mul_point(on.matrix, cur.point);
                     cur.t = length(point - ray.source);
@@ -415,7 +494,7 @@ __device__ __forceinline__ void scene_trace(const DScene& sc, Ray ray, bool brut
         const DNode& nd = sc.nodes[i];
         uint32_t type = nd.type;
         if (type == 0u) { // collection
-            if (depth > 0) saved_best[depth] = best;
+            if (depth > 0) spill_store_hit(st, depth, best);
             depth++;
             open = i;
             best.hit = 0u;
@@ -425,7 +504,7 @@ __device__ __forceinline__ void scene_trace(const DScene& sc, Ray ray, bool brut
             continue;
         }
         if (type == 1u) { // transform
-            saved_ray[depth] = ray;
+            spill_store_ray(st, depth, ray);
             depth++;
             open = i;
             ray = apply_transform(ray, nd.matrix_inverse, nd.inverse_normal_matrix);

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime_api.h>
 #include <hip/hip_vector_types.h>
 
+#include <vector>
+
 #include "../../../include/pathtracing_amd.h"
 #include "pt_scene_device.h"
 
@@ -19,7 +21,13 @@ struct Workspace {
     uint32_t* counters = nullptr; // kMaxDepthCounters queue lengths
     uint64_t capacity_paths = 0;
     uint64_t* ray_total = nullptr; // device-side running sum of traced rays
+    // Trace kernels run a persistent grid of `persistent_blocks` blocks; `spill`
+    // holds one column of spill_dwords() dwords per thread of that grid.
+    uint32_t* spill = nullptr;
+    uint32_t persistent_blocks = 0;
 };
+size_t spill_dwords_per_thread();
+constexpr uint32_t kTraceBlock = 256;
 constexpr uint32_t kMaxDepthCounters = 4096;
 
 struct BatchGeometry {
@@ -31,15 +39,18 @@ struct BatchGeometry {
 // Runs samples [sample_first, sample_first + sample_count) of every pixel of the
 // rectangle and adds their colours, in sample order, into d_accum (camera-space
 // layout, (x + y*W)*3).
+// `segment_events`: when non-null, a pair of events (start, stop) is created and
+// recorded around every path-segment kernel launch and appended to the vector.
 hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeometry& geo, uint64_t seed,
                         uint64_t sample_first, uint32_t sample_count, uint32_t trace_depth, bool brute,
-                        Workspace& ws, float* d_accum, hipStream_t stream);
+                        Workspace& ws, float* d_accum, hipStream_t stream,
+                        std::vector<hipEvent_t>* segment_events);
 
 hipError_t resolve_image(const float* d_accum, uint32_t width, uint32_t height, float scale, float* d_out,
                          hipStream_t stream);
 
 hipError_t trace_closest(const DScene& scene, const PtRay* d_rays, size_t n, bool brute, PtHit* d_hits,
-                         hipStream_t stream);
+                         const Workspace& ws, hipStream_t stream);
 
 hipError_t generate_rays(const DCamera& cam, uint64_t seed, const uint32_t* d_pixel_xy, const uint64_t* d_sample,
                          size_t n, PtRay* d_rays, hipStream_t stream);

@@ -13,6 +13,8 @@
 #include "pt_device.h"
 #include "pt_kernels.h"
 
+#include <algorithm>
+
 namespace ptk {
 
 constexpr int kBlock = 256;
@@ -83,77 +85,91 @@ __global__ void __launch_bounds__(kBlock) raygen_kernel(RenderParams p, float4* 
     (void)contrib;
 }
 
-__global__ void __launch_bounds__(kBlock) bounce_kernel(RenderParams p, uint32_t depth, const float4* __restrict__ ia,
+__device__ __forceinline__ TravStack make_stack(int32_t* lds_stack, uint32_t* spill, uint32_t spill_threads) {
+    TravStack st;
+    st.lds = &lds_stack[threadIdx.x];
+    st.stride = kBlock;
+    st.spill = spill + (blockIdx.x * kBlock + threadIdx.x);
+    st.spill_stride = spill_threads;
+    st.sp = 0;
+    return st;
+}
+
+// Persistent grid: wave w of the launch takes queue chunks w, w + W, w + 2W, ...
+// of 64 consecutive records (W = waves in the grid), so neighbouring chunks --
+// neighbouring pixels on the first segment -- are in flight together.
+__global__ void __launch_bounds__(kBlock, 4) bounce_kernel(RenderParams p, uint32_t depth, const float4* __restrict__ ia,
                                                         const float4* __restrict__ ib, const float4* __restrict__ ic,
                                                         float4* oa, float4* ob, float4* oc, uint32_t* counters,
-                                                        float* contrib, unsigned long long* ray_total) {
+                                                        float* contrib, unsigned long long* ray_total,
+                                                        uint32_t* spill, uint32_t spill_threads) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
-    uint32_t count = counters[depth];
-    uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
-    if (gid == 0) atomicAdd(ray_total, (unsigned long long)count);
-    // whole waves past the end of the queue leave; a partial wave stays for the ballot
-    if ((gid & ~63u) >= count) return;
-    bool active = gid < count;
-    bool next_alive = false;
-    Ray nray;
-    V3 nmult = mk3(0, 0, 0);
-    uint32_t path = 0, rng_counter = 0;
-    if (active) {
-        float4 a = ia[gid], b = ib[gid], c = ic[gid];
-        Ray ray;
-        ray.source = mk3(a.x, a.y, a.z);
-        ray.min = a.w;
-        ray.direction = mk3(b.x, b.y, b.z);
-        ray.max = kF32Max;
-        path = __float_as_uint(b.w);
-        V3 mult = mk3(c.x, c.y, c.z);
-        rng_counter = __float_as_uint(c.w);
+    const uint32_t count = counters[depth];
+    const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
+    if (tid == 0) atomicAdd(ray_total, (unsigned long long)count);
+    const uint32_t grid_threads = gridDim.x * kBlock;
+    TravStack st = make_stack(lds_stack, spill, spill_threads);
+    for (uint32_t base = tid & ~63u; base < count; base += grid_threads) {
+        const uint32_t gid = base + (tid & 63u);
+        bool active = gid < count;
+        bool next_alive = false;
+        Ray nray;
+        V3 nmult = mk3(0, 0, 0);
+        uint32_t path = 0, rng_counter = 0;
+        if (active) {
+            float4 a = ia[gid], b = ib[gid], c = ic[gid];
+            Ray ray;
+            ray.source = mk3(a.x, a.y, a.z);
+            ray.min = a.w;
+            ray.direction = mk3(b.x, b.y, b.z);
+            ray.max = kF32Max;
+            path = __float_as_uint(b.w);
+            V3 mult = mk3(c.x, c.y, c.z);
+            rng_counter = __float_as_uint(c.w);
 
-        TravStack st;
-        st.lds = &lds_stack[threadIdx.x];
-        st.stride = kBlock;
-        st.sp = 0;
-        Hit hit;
-        scene_trace(p.scene, ray, p.brute != 0u, st, &hit);
+            Hit hit;
+            scene_trace(p.scene, ray, p.brute != 0u, st, &hit);
 
-        V3 color = mk3(0, 0, 0);
-        bool finished = true;
-        if (hit.hit) {
-            uint32_t s_local = path / p.geo.npp, q = path % p.geo.npp;
-            uint32_t x, y;
-            bool valid;
-            path_slot_to_pixel(p.geo, q, &x, &y, &valid);
-            Rng rng;
-            rng.key = stream_key(p.seed, stream_id(p.sample_first + s_local, (uint64_t)x + (uint64_t)y * p.cam.width));
-            rng.counter = rng_counter;
-            V3 av, dir;
-            bool is_color = material_get_color(p.scene.materials[hit.material_id], ray.direction, hit, rng, &av, &dir);
-            rng_counter = rng.counter;
-            if (is_color) {
-                color = mult * av; // work_group.rs:39-41
-            } else if (depth + 1u < p.trace_depth) {
-                // work_group.rs:42-46
-                nray.source = hit.point + dir * kEpsilon;
-                nray.direction = dir;
-                nray.min = kEpsilon;
-                nray.max = kF32Max;
-                nmult = mult * av;
-                finished = false;
-                next_alive = true;
+            V3 color = mk3(0, 0, 0);
+            bool finished = true;
+            if (hit.hit) {
+                uint32_t s_local = path / p.geo.npp, q = path % p.geo.npp;
+                uint32_t x, y;
+                bool valid;
+                path_slot_to_pixel(p.geo, q, &x, &y, &valid);
+                Rng rng;
+                rng.key = stream_key(p.seed, stream_id(p.sample_first + s_local, (uint64_t)x + (uint64_t)y * p.cam.width));
+                rng.counter = rng_counter;
+                V3 av, dir;
+                bool is_color =
+                    material_get_color(p.scene.materials[hit.material_id], ray.direction, hit, rng, &av, &dir);
+                rng_counter = rng.counter;
+                if (is_color) {
+                    color = mult * av; // work_group.rs:39-41
+                } else if (depth + 1u < p.trace_depth) {
+                    // work_group.rs:42-46
+                    nray.source = hit.point + dir * kEpsilon;
+                    nray.direction = dir;
+                    nray.min = kEpsilon;
+                    nray.max = kF32Max;
+                    nmult = mult * av;
+                    finished = false;
+                    next_alive = true;
+                }
+            }
+            if (finished) {
+                float* dst = contrib + (size_t)path * 3;
+                dst[0] = color.x;
+                dst[1] = color.y;
+                dst[2] = color.z;
             }
         }
-        if (finished) {
-            float* dst = contrib + (size_t)path * 3;
-            dst[0] = color.x;
-            dst[1] = color.y;
-            dst[2] = color.z;
+        uint32_t slot = queue_reserve(next_alive, &counters[depth + 1u]);
+        if (next_alive) {
+            oa[slot] = make_float4(nray.source.x, nray.source.y, nray.source.z, nray.min);
+            ob[slot] = make_float4(nray.direction.x, nray.direction.y, nray.direction.z, __uint_as_float(path));
+            oc[slot] = make_float4(nmult.x, nmult.y, nmult.z, __uint_as_float(rng_counter));
         }
-    }
-    uint32_t slot = queue_reserve(next_alive, &counters[depth + 1u]);
-    if (next_alive) {
-        oa[slot] = make_float4(nray.source.x, nray.source.y, nray.source.z, nray.min);
-        ob[slot] = make_float4(nray.direction.x, nray.direction.y, nray.direction.z, __uint_as_float(path));
-        oc[slot] = make_float4(nmult.x, nmult.y, nmult.z, __uint_as_float(rng_counter));
     }
 }
 
@@ -193,34 +209,33 @@ __global__ void __launch_bounds__(kBlock) resolve_kernel(const float* __restrict
     dst[2] = src[2] * scale;
 }
 
-__global__ void __launch_bounds__(kBlock) trace_closest_kernel(DScene scene, const PtRay* __restrict__ rays, size_t n,
-                                                               uint32_t brute, PtHit* hits) {
+__global__ void __launch_bounds__(kBlock, 4) trace_closest_kernel(DScene scene, const PtRay* __restrict__ rays, size_t n,
+                                                               uint32_t brute, PtHit* hits, uint32_t* spill,
+                                                               uint32_t spill_threads) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
-    size_t gid = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (gid >= n) return;
-    PtRay r = rays[gid];
-    Ray ray;
-    ray.source = mk3(r.source.x, r.source.y, r.source.z);
-    ray.direction = mk3(r.direction.x, r.direction.y, r.direction.z);
-    ray.min = r.min;
-    ray.max = r.max;
-    TravStack st;
-    st.lds = &lds_stack[threadIdx.x];
-    st.stride = kBlock;
-    st.sp = 0;
-    Hit h;
-    scene_trace(scene, ray, brute != 0u, st, &h);
-    PtHit o;
-    o.hit = h.hit;
-    o.hit_inside = h.hit_inside;
-    o.node_index = h.hit ? h.node_index : 0xFFFFFFFFu;
-    o.tri_index = h.hit ? h.tri_index : 0xFFFFFFFFu;
-    o.material_id = h.material_id;
-    o.t = h.t;
-    o.point = {h.point.x, h.point.y, h.point.z};
-    o.normal = {h.normal.x, h.normal.y, h.normal.z};
-    o.uv = {h.uv.x, h.uv.y};
-    hits[gid] = o;
+    TravStack st = make_stack(lds_stack, spill, spill_threads);
+    const size_t grid_threads = (size_t)gridDim.x * kBlock;
+    for (size_t gid = (size_t)blockIdx.x * kBlock + threadIdx.x; gid < n; gid += grid_threads) {
+        PtRay r = rays[gid];
+        Ray ray;
+        ray.source = mk3(r.source.x, r.source.y, r.source.z);
+        ray.direction = mk3(r.direction.x, r.direction.y, r.direction.z);
+        ray.min = r.min;
+        ray.max = r.max;
+        Hit h;
+        scene_trace(scene, ray, brute != 0u, st, &h);
+        PtHit o;
+        o.hit = h.hit;
+        o.hit_inside = h.hit_inside;
+        o.node_index = h.hit ? h.node_index : 0xFFFFFFFFu;
+        o.tri_index = h.hit ? h.tri_index : 0xFFFFFFFFu;
+        o.material_id = h.material_id;
+        o.t = h.t;
+        o.point = {h.point.x, h.point.y, h.point.z};
+        o.normal = {h.normal.x, h.normal.y, h.normal.z};
+        o.uv = {h.uv.x, h.uv.y};
+        hits[gid] = o;
+    }
 }
 
 __global__ void __launch_bounds__(kBlock) generate_rays_kernel(DCamera cam, uint64_t seed,
@@ -272,11 +287,15 @@ __global__ void __launch_bounds__(kBlock) shade_kernel(DScene scene, const PtVec
 
 // ------------------------------------------------------------------ launchers
 
+size_t spill_dwords_per_thread() { return (size_t)kSpillDwords; }
+static_assert(kTraceBlock == (uint32_t)kBlock, "block size mismatch");
+
 static inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
 hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeometry& geo, uint64_t seed,
                         uint64_t sample_first, uint32_t sample_count, uint32_t trace_depth, bool brute,
-                        Workspace& ws, float* d_accum, hipStream_t stream) {
+                        Workspace& ws, float* d_accum, hipStream_t stream,
+                        std::vector<hipEvent_t>* segment_events) {
     RenderParams p;
     p.scene = scene;
     p.cam = cam;
@@ -288,7 +307,7 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
     p.brute = brute ? 1u : 0u;
     uint64_t total = (uint64_t)sample_count * geo.npp;
     if (total == 0 || trace_depth == 0) return hipSuccess;
-    if (total > ws.capacity_paths || total > 0xFFFFFFFFull || trace_depth + 1u > kMaxDepthCounters)
+    if (total > ws.capacity_paths || total > 0xFFFFFFFFull || trace_depth + 1u > kMaxDepthCounters || !ws.spill)
         return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(ws.counters, 0, sizeof(uint32_t) * (trace_depth + 1u), stream);
     if (e != hipSuccess) return e;
@@ -297,10 +316,20 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
                                                              ws.counters, ws.contrib);
     for (uint32_t d = 0; d < trace_depth; d++) {
         int in = d & 1, out = in ^ 1;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (segment_events) {
+            if ((e = hipEventCreate(&e0)) != hipSuccess) return e;
+            if ((e = hipEventCreate(&e1)) != hipSuccess) return e;
+            segment_events->push_back(e0);
+            segment_events->push_back(e1);
+            if ((e = hipEventRecord(e0, stream)) != hipSuccess) return e;
+        }
         // the queue cannot be longer than the batch; the kernel reads the real length
-        bounce_kernel<<<blocks_for(total), kBlock, 0, stream>>>(
+        bounce_kernel<<<std::min(blocks_for(total), ws.persistent_blocks), kBlock, 0, stream>>>(
             p, d, ws.queue[in][0], ws.queue[in][1], ws.queue[in][2], ws.queue[out][0], ws.queue[out][1],
-            ws.queue[out][2], ws.counters, ws.contrib, reinterpret_cast<unsigned long long*>(ws.ray_total));
+            ws.queue[out][2], ws.counters, ws.contrib, reinterpret_cast<unsigned long long*>(ws.ray_total), ws.spill,
+            ws.persistent_blocks * kBlock);
+        if (segment_events && (e = hipEventRecord(e1, stream)) != hipSuccess) return e;
     }
     accumulate_kernel<<<blocks_for(geo.npp), kBlock, 0, stream>>>(geo, cam.width, sample_count, ws.contrib, d_accum);
     return hipGetLastError();
@@ -315,9 +344,10 @@ hipError_t resolve_image(const float* d_accum, uint32_t width, uint32_t height, 
 }
 
 hipError_t trace_closest(const DScene& scene, const PtRay* d_rays, size_t n, bool brute, PtHit* d_hits,
-                         hipStream_t stream) {
+                         const Workspace& ws, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    trace_closest_kernel<<<blocks_for(n), kBlock, 0, stream>>>(scene, d_rays, n, brute ? 1u : 0u, d_hits);
+    trace_closest_kernel<<<std::min(blocks_for(n), ws.persistent_blocks), kBlock, 0, stream>>>(
+        scene, d_rays, n, brute ? 1u : 0u, d_hits, ws.spill, ws.persistent_blocks * kBlock);
     return hipGetLastError();
 }
 
