@@ -290,6 +290,12 @@ PtStatus pt_render_task_parse(const char* json_text, PtRenderTask* out_task,
 PtStatus pt_tree_build(const PtMeshDesc* mesh, uint8_t** out_data, uint64_t* out_size);
 void pt_buffer_free(uint8_t* data);
 
+/* PT_OK when `blob` is a well-formed tree for exactly this mesh: right version and
+ * geometry hash, every triangle in exactly one leaf, depth within the traversal
+ * stack, every box enclosing the padded bounds of what lies below it.  A blob that
+ * fails is never used: pt_scene_create rebuilds instead (PT_ERR_PARSE here). */
+PtStatus pt_tree_validate(const PtMeshDesc* mesh, const uint8_t* data, uint64_t size);
+
 /* ---------------------------------------------------------- result codecs */
 
 /* RenderedImage::to_bytes (worker/src/lib.rs:56-62): u32 LE width, u32 LE height,

@@ -199,6 +199,7 @@ SYMBOLS = {
     "pt_render_task_parse": (C.c_int, [C.c_char_p, C.POINTER(PtRenderTask), C.c_char_p, C.c_size_t]),
     "pt_tree_build": (C.c_int, [C.POINTER(PtMeshDesc), C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]),
     "pt_buffer_free": (None, [C.POINTER(C.c_uint8)]),
+    "pt_tree_validate": (C.c_int, [C.POINTER(PtMeshDesc), _VOIDP, C.c_uint64]),
     "pt_rendered_image_to_bytes": (C.c_int, [_VOIDP, C.c_uint32, C.c_uint32, _VOIDP, C.c_size_t]),
 }
 

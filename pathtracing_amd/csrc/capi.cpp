@@ -644,6 +644,15 @@ PtStatus pt_tree_build(const PtMeshDesc* mesh, uint8_t** out_data, uint64_t* out
 
 void pt_buffer_free(uint8_t* data) { free(data); }
 
+PtStatus pt_tree_validate(const PtMeshDesc* mesh, const uint8_t* data, uint64_t size) {
+    return guarded([&] {
+        if (!mesh || !data || (mesh->triangle_count && !mesh->positions)) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        pt::BuiltBvh bvh;
+        if (!pt::deserialize_tree(data, size, mesh->positions, mesh->triangle_count, &bvh))
+            throw Error(PT_ERR_PARSE, "not a valid tree for this mesh");
+    });
+}
+
 PtStatus pt_rendered_image_to_bytes(const float* rgb, uint32_t width, uint32_t height, uint8_t* out, size_t out_cap) {
     return guarded([&] {
         if (!rgb || !out) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");

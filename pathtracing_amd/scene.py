@@ -23,11 +23,16 @@ class Scene:
 
     @property
     def desc(self) -> N.PtSceneDesc:
-        return N.lib.pt_host_scene_desc(self._handle).contents
+        d = N.lib.pt_host_scene_desc(self._handle).contents
+        d._owner = self  # the arrays it points into live as long as this Scene
+        return d
 
     @property
     def desc_pointer(self):
-        return N.lib.pt_host_scene_desc(self._handle)
+        """Pointer to the PtSceneDesc; it keeps this Scene (which owns the arrays) alive."""
+        p = N.lib.pt_host_scene_desc(self._handle)
+        p._owner = self
+        return p
 
     def close(self) -> None:
         if self._handle:
@@ -39,3 +44,19 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+
+def build_tree(mesh_desc: N.PtMeshDesc) -> bytes:
+    """Serialised acceleration structure (".tree" contents) for one mesh of a scene."""
+    data = C.POINTER(C.c_uint8)()
+    size = C.c_uint64()
+    N.check(N.lib.pt_tree_build(C.byref(mesh_desc), C.byref(data), C.byref(size)))
+    try:
+        return C.string_at(data, size.value)
+    finally:
+        N.lib.pt_buffer_free(data)
+
+
+def validate_tree(mesh_desc: N.PtMeshDesc, blob: bytes) -> bool:
+    buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob) if blob else (C.c_uint8 * 1)()
+    return N.lib.pt_tree_validate(C.byref(mesh_desc), C.cast(buf, C.c_void_p), len(blob)) == N.PT_OK

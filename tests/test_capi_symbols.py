@@ -1,0 +1,71 @@
+"""The shared library loads without a GPU and exports exactly what the header declares."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+import pathtracing_amd as P
+from pathtracing_amd import _native as N
+from tests import helpers as H
+
+
+def header_functions():
+    with open(os.path.join(H.ROOT, "include", "pathtracing_amd.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return set(re.findall(r"\b(pt_[a-z_0-9]+)\s*\(", text))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    declared = header_functions()
+    assert declared == set(N.SYMBOLS), declared ^ set(N.SYMBOLS)
+    raw = C.CDLL(N.LIB_PATH)
+    for name in declared:
+        assert getattr(raw, name) is not None
+    assert N.lib.pt_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof / offsetof as a C compiler sees include/pathtracing_amd.h against the ctypes mirrors."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        import pytest
+
+        pytest.skip("no C compiler")
+    structs = ["PtVec2", "PtVec3", "PtMat3", "PtMat4", "PtRay", "PtNodeDesc", "PtMeshDesc", "PtMaterialDesc", "PtImageDesc",
+               "PtTreeBlob", "PtSceneDesc", "PtCamera", "PtRenderTask", "PtRenderOpts", "PtRenderStats", "PtHit"]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pathtracing_amd.h"', "int main(void) {"]
+    for name in structs:
+        lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
+        for field, _ in getattr(N, name)._fields_:
+            lines.append(f'printf("{name}.{field} %zu\\n", offsetof({name}, {field}));')
+    lines.append("return 0; }")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(H.ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for name in structs:
+        cls = getattr(N, name)
+        assert int(got[name]) == C.sizeof(cls), name
+        for field, _ in cls._fields_:
+            assert int(got[f"{name}.{field}"]) == getattr(cls, field).offset, f"{name}.{field}"
+
+
+def test_k6_wire_bytes():
+    # RenderedImage::to_bytes, lib.rs:56-62: u32 LE w, u32 LE h, then w*h*3 f32 LE
+    img = np.array([[[1, 2, 3], [4, 5, 6]]], dtype=np.float32)
+    raw = P.RenderedImage(img).to_bytes()
+    assert raw[:8] == bytes.fromhex("0200000001000000")
+    assert np.array_equal(np.frombuffer(raw[8:], dtype="<f4"), np.arange(1, 7, dtype=np.float32))
+    assert np.array_equal(P.RenderedImage.from_bytes(raw).image, img)
+
+
+def test_errors_are_status_codes_not_aborts():
+    h = C.c_void_p()
+    assert N.lib.pt_scene_create(None, 0, C.byref(h)) == 1  # PT_ERR_INVALID_ARGUMENT
+    assert "null" in N.last_error()
+    task = N.PtRenderTask()
+    assert N.lib.pt_render(None, C.byref(task), None, None, None) == 1

@@ -1,0 +1,104 @@
+"""The ".tree" acceleration-structure file: build, validation, rejection of stale or
+damaged files (host code only).  The reference's kd_tree resource is a stub
+(scene/mod.rs:94-96) and scene_data/cube.tree is empty, so the format is this
+project's own; what it must guarantee is that a file can never make the search
+disagree with the linear scan."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import pathtracing_amd as P
+from pathtracing_amd import scene as S
+from pathtracing_amd import synth
+from tests import helpers as H
+from tests.test_host_loader import load_obj_text
+
+
+@pytest.fixture(scope="module")
+def knot(tmp_path_factory):
+    d = tmp_path_factory.mktemp("knot")
+    verts, tris = synth.knot_mesh(96, 40)
+    synth.write_obj(str(d / "m.obj"), verts, tris)
+    with open(d / "m.obj") as f:
+        text = f.read()
+    return load_obj_text(d, text)
+
+
+def test_build_validate_roundtrip(knot):
+    mesh = knot.desc.meshes[0]
+    assert mesh.triangle_count == 2 * 96 * 40
+    blob = S.build_tree(mesh)
+    assert blob[:8] == b"PTAMDTRE"
+    assert S.validate_tree(mesh, blob)
+    assert S.build_tree(mesh) == blob  # deterministic
+    cube = P.Scene.load(H.SCENE_DATA, "./simple_scene.json")
+    cube_blob = S.build_tree(cube.desc.meshes[0])
+    assert S.validate_tree(cube.desc.meshes[0], cube_blob)
+    # a tree built for other geometry is refused (hash of the positions)
+    assert not S.validate_tree(cube.desc.meshes[0], blob)
+    assert not S.validate_tree(mesh, cube_blob)
+
+
+def test_damaged_files_are_refused(knot):
+    mesh = knot.desc.meshes[0]
+    blob = bytearray(S.build_tree(mesh))
+    assert not S.validate_tree(mesh, b"")            # the shipped cube.tree: empty -> rebuild
+    assert not S.validate_tree(mesh, bytes(blob[:100]))
+    assert not S.validate_tree(mesh, bytes(blob) + b"\0")
+    bad = bytearray(blob)
+    bad[8] ^= 1                                       # version
+    assert not S.validate_tree(mesh, bytes(bad))
+    header = 8 + 4 + 4 + 8 + 8 + 4 + 4 + 24 + 8
+    node_count = struct.unpack_from("<Q", blob, 24)[0]
+    assert node_count > 1000
+    # shrink one box of the first node: no longer encloses what is below it
+    bad = bytearray(blob)
+    lmax_x = struct.unpack_from("<f", bad, header + 12)[0]
+    lmin_x = struct.unpack_from("<f", bad, header)[0]
+    struct.pack_into("<f", bad, header + 12, (lmax_x + lmin_x) / 2)
+    assert not S.validate_tree(mesh, bytes(bad))
+    # point a child at itself: a node visited twice
+    bad = bytearray(blob)
+    struct.pack_into("<i", bad, header + 48, 0)
+    assert not S.validate_tree(mesh, bytes(bad))
+    # duplicate a triangle in the leaf order: one triangle twice, one missing
+    bad = bytearray(blob)
+    order_off = header + node_count * 64
+    first = struct.unpack_from("<I", bad, order_off)[0]
+    struct.pack_into("<I", bad, order_off + 4, first)
+    assert not S.validate_tree(mesh, bytes(bad))
+
+
+def test_oracle_bvh_equals_scan_on_dense_mesh(knot, oracle):
+    """The oracle's own BVH mode against its literal scan on a 7,680-triangle mesh: random
+    rays, rays through vertices and edge midpoints, near-tangent rays."""
+    sc = oracle.scene(knot.desc_pointer)
+    verts, tris = synth.knot_mesh(96, 40)
+    rng = np.random.default_rng(3)
+    rays = [H.random_rays(6000, seed=1, origin_box=14, target_box=9)]
+    t = verts[tris[rng.integers(0, tris.shape[0], 1500)]]
+    targets = np.concatenate([t[:, 0], (t[:, 0] + t[:, 1]) / 2, (t[:, 0] + t[:, 1] + t[:, 2]) / 3])
+    e0, e1 = t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]
+    nrm = np.cross(e0, e1)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    tang = e0 / np.linalg.norm(e0, axis=1, keepdims=True)
+    src = np.concatenate([np.tile(np.array([[1.0, 2.0, 30.0]], np.float32), (3000, 1)),
+                          (t[:, 0] + t[:, 1] + t[:, 2]) / 3 + nrm * 0.01 + tang * 2.0]).astype(np.float32)
+    d = (targets - src).astype(np.float64)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r = np.zeros((src.shape[0], 8), np.float32)
+    r[:, :3], r[:, 3:6], r[:, 7] = src, d.astype(np.float32), H.F32_MAX
+    rays.append(r)
+    # non-finite rays: the scan rejects every triangle, the BVH mode answers the same at once
+    weird = H.random_rays(8, seed=2)
+    weird[0, 0] = np.nan
+    weird[1, 4] = np.nan
+    weird[2, 3] = np.inf
+    weird[3, 2] = -np.inf
+    rays.append(weird)
+    rays = np.concatenate(rays)
+    lin = sc.trace(rays, accel=0)
+    H.assert_hits_identical(sc.trace(rays, accel=1), lin, "oracle BVH vs scan, dense mesh")
+    assert lin["hit"][:6000].mean() > 0.2 and not lin["hit"][-8:-4].any()
