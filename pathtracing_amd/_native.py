@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpathtracing_amd.so")
+# PATHTRACING_AMD_LIB selects another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("PATHTRACING_AMD_LIB") or os.path.join(_HERE, "libpathtracing_amd.so")
 
 PT_OK = 0
 PT_NO_INDEX = 0xFFFFFFFF

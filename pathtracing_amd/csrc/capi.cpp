@@ -90,36 +90,40 @@ struct PtScene {
         if (ws.contrib) (void)hipFree(ws.contrib);
         ws.contrib = nullptr;
         ws.capacity_paths = 0;
+        ws.contrib_paths = 0;
     }
-    // Fixed state of the trace kernels: counters and the spill columns of the
-    // persistent grid (4 blocks of 256 threads per compute unit).
+    // Fixed state of the trace kernels: the spill columns and per-wave queue
+    // counters of the persistent grid (4 blocks of 256 threads per compute unit).
     void ensure_trace_state() {
         if (ws.spill) return;
         hipDeviceProp_t prop;
         hip_check(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
         uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
-        ws.persistent_blocks = cus * 4u;
+        ws.persistent_blocks = cus * ptk::segment_blocks_per_cu();
         size_t bytes = (size_t)ws.persistent_blocks * ptk::kTraceBlock * ptk::spill_dwords_per_thread() * sizeof(uint32_t);
         hip_check(hipMalloc(reinterpret_cast<void**>(&ws.spill), bytes), "hipMalloc spill");
+        size_t waves = (size_t)ws.persistent_blocks * (ptk::kTraceBlock / 64);
+        for (int q = 0; q < 2; q++)
+            hip_check(hipMalloc(reinterpret_cast<void**>(&ws.wave_counts[q]), waves * sizeof(uint32_t)), "hipMalloc counts");
+        hip_check(hipMalloc(reinterpret_cast<void**>(&ws.ray_total), sizeof(uint64_t)), "hipMalloc ray_total");
     }
     void ensure_workspace(uint64_t paths) {
         ensure_trace_state();
-        if (!ws.counters) {
-            hip_check(hipMalloc(reinterpret_cast<void**>(&ws.counters), sizeof(uint32_t) * ptk::kMaxDepthCounters),
-                      "hipMalloc counters");
-            hip_check(hipMalloc(reinterpret_cast<void**>(&ws.ray_total), sizeof(uint64_t)), "hipMalloc ray_total");
-        }
-        if (paths <= ws.capacity_paths) return;
+        uint32_t waves = ws.persistent_blocks * (ptk::kTraceBlock / 64);
+        uint64_t records = (uint64_t)ptk::queue_region_capacity(paths, waves) * waves;
+        if (records <= ws.capacity_paths && paths <= ws.contrib_paths) return;
         free_workspace();
         for (int q = 0; q < 2; q++)
             for (int k = 0; k < 3; k++)
-                hip_check(hipMalloc(reinterpret_cast<void**>(&ws.queue[q][k]), paths * sizeof(float4)), "hipMalloc queue");
+                hip_check(hipMalloc(reinterpret_cast<void**>(&ws.queue[q][k]), records * sizeof(float4)), "hipMalloc queue");
         hip_check(hipMalloc(reinterpret_cast<void**>(&ws.contrib), paths * 3 * sizeof(float)), "hipMalloc contrib");
-        ws.capacity_paths = paths;
+        ws.capacity_paths = records;
+        ws.contrib_paths = paths;
     }
     ~PtScene() {
         free_workspace();
-        if (ws.counters) (void)hipFree(ws.counters);
+        for (int q = 0; q < 2; q++)
+            if (ws.wave_counts[q]) (void)hipFree(ws.wave_counts[q]);
         if (ws.ray_total) (void)hipFree(ws.ray_total);
         if (ws.spill) (void)hipFree(ws.spill);
         for (void* p : allocs) (void)hipFree(p);
@@ -314,7 +318,7 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
     memset(&o, 0, sizeof(o));
     if (opts_in) o = *opts_in;
     ptk::DCamera cam = make_camera(task->camera);
-    if (task->trace_depth + 1 > ptk::kMaxDepthCounters) throw Error(PT_ERR_UNSUPPORTED, "trace_depth above 4094");
+    if (task->trace_depth > 0xFFFFFFFEull) throw Error(PT_ERR_UNSUPPORTED, "trace_depth above 2^32");
     if (o.sample_offset + task->iterations > 0xFFFFFFFFull) throw Error(PT_ERR_UNSUPPORTED, "sample index above 2^32");
     uint32_t x0 = 0, y0 = 0, w = cam.width, h = cam.height;
     if (o.tile_w && o.tile_h) {

@@ -281,38 +281,23 @@ __device__ __forceinline__ Hit spill_load_hit(const TravStack& st, int depth) {
     return h;
 }
 
-// Entry distance of the ray into a padded box, or +inf when it misses on
-// [0, limit].  NaN slab terms (0 * inf) do not constrain.
-__device__ __forceinline__ float box_entry(const float* bmin, const float* bmax, V3 o, V3 inv, float limit) {
-    float t0 = 0.0f, t1 = limit;
-    {
-        float ta = (bmin[0] - o.x) * inv.x, tb = (bmax[0] - o.x) * inv.x;
-        float lo = fminf(ta, tb), hi = fmaxf(ta, tb);
-        bool ok = (ta == ta) && (tb == tb);
-        lo = ok ? lo - abs_f(lo) * 4e-7f : 0.0f;
-        hi = ok ? hi + abs_f(hi) * 4e-7f : limit;
-        t0 = fmaxf(t0, lo);
-        t1 = fminf(t1, hi);
-    }
-    {
-        float ta = (bmin[1] - o.y) * inv.y, tb = (bmax[1] - o.y) * inv.y;
-        float lo = fminf(ta, tb), hi = fmaxf(ta, tb);
-        bool ok = (ta == ta) && (tb == tb);
-        lo = ok ? lo - abs_f(lo) * 4e-7f : 0.0f;
-        hi = ok ? hi + abs_f(hi) * 4e-7f : limit;
-        t0 = fmaxf(t0, lo);
-        t1 = fminf(t1, hi);
-    }
-    {
-        float ta = (bmin[2] - o.z) * inv.z, tb = (bmax[2] - o.z) * inv.z;
-        float lo = fminf(ta, tb), hi = fmaxf(ta, tb);
-        bool ok = (ta == ta) && (tb == tb);
-        lo = ok ? lo - abs_f(lo) * 4e-7f : 0.0f;
-        hi = ok ? hi + abs_f(hi) * 4e-7f : limit;
-        t0 = fmaxf(t0, lo);
-        t1 = fminf(t1, hi);
-    }
-    return (t0 <= t1) ? t0 : f32_inf();
+// Conservative slab test of a padded box against the ray interval [0, limit].
+// The computed interval is widened by 4e-7 relative (the slab arithmetic rounds
+// with less than 2e-7).  A NaN term arises only as 0 * inf, i.e. for a ray lying
+// exactly in one of the box's boundary planes; min/max drop it and the other
+// plane's +-inf then reports a miss, which is right: boxes are padded by more
+// than the distance at which the f32 triangle test can still accept a ray, so
+// such a ray cannot be accepted by any triangle inside.
+__device__ __forceinline__ bool box_test(const float* bmin, const float* bmax, V3 o, V3 inv, float limit, float* entry) {
+    float ax = (bmin[0] - o.x) * inv.x, bx = (bmax[0] - o.x) * inv.x;
+    float ay = (bmin[1] - o.y) * inv.y, by = (bmax[1] - o.y) * inv.y;
+    float az = (bmin[2] - o.z) * inv.z, bz = (bmax[2] - o.z) * inv.z;
+    float lo = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    float hi = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), limit));
+    lo = lo * 0.9999996f;
+    hi = hi * 1.0000004f;
+    *entry = lo;
+    return lo <= hi;
 }
 
 __device__ __forceinline__ LeafTri load_tri(const LeafTri* p) {
@@ -330,80 +315,93 @@ __device__ __forceinline__ bool all_finite(V3 v) {
     return ((__float_as_uint(v.x) & e) != e) && ((__float_as_uint(v.y) & e) != e) && ((__float_as_uint(v.z) & e) != e);
 }
 
-// Closest triangle of `mesh` for `ray` (object space).  best_t starts at +inf;
-// on return *slot is the leaf-order (or, brute force, original-order) position
-// of the winning triangle, *orig its original index.
-__device__ __forceinline__ bool mesh_closest_bvh(const DMesh& mesh, const Ray& ray, TravStack& st, float* best_t,
-                                                 uint32_t* slot, uint32_t* orig) {
-    V3 inv = mk3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
-    float tbest = f32_inf();
-    uint32_t best_orig = 0xFFFFFFFFu, best_slot = 0u;
-    bool found = false;
+// State of one lane's search through a mesh's BVH.  The search must return what
+// the linear scan of mesh/mod.rs:57-62 returns: the smallest t, the lowest
+// triangle index among equal t.  It is cut into steps so that a wave can stop,
+// hand finished lanes new rays and go on (see bounce_kernel).
+struct TravState {
+    const BvhNode* nodes;
+    const LeafTri* tris;
+    V3 inv;
+    float ray_limit; // ray.max, or +inf when it is NaN (a NaN max never rejects, triangle/mod.rs:155)
+    int32_t cur;     // node to visit next: >= 0 inner, < 0 leaf, kBvhSentinel finished
+    float tbest;
+    uint32_t best_slot, best_orig, found;
+};
+
+// Starts a search.  False: the ray cannot hit the mesh at all.
+__device__ __forceinline__ bool trav_begin(const DMesh& mesh, const Ray& ray, TravStack& st, TravState& ts) {
     // A ray with a NaN or infinite origin or direction component cannot hit any
     // triangle: in triangle_hit the non-finite value reaches u = (tvec.pvec)/det
     // as an infinity or a NaN and fails 0 <= u <= 1 (the linear scan would test
     // every triangle and reject every one).  Such rays do occur: the reference's
     // cosine-weighted sampler takes sqrt(cos(f32 pi/2)) = sqrt(-4.4e-8) when its
-    // random number is exactly 0.  Without this exit the slab test, which must
-    // not cull on NaN, would walk the whole tree.
+    // random number is exactly 0.
     if (!all_finite(ray.source) || !all_finite(ray.direction)) return false;
-    float ray_limit = (ray.max == ray.max) ? ray.max : f32_inf();
-    if (box_entry(mesh.bmin, mesh.bmax, ray.source, inv, ray_limit) == f32_inf()) return false;
+    ts.inv = mk3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
+    ts.ray_limit = (ray.max == ray.max) ? ray.max : f32_inf();
+    float entry;
+    if (!box_test(mesh.bmin, mesh.bmax, ray.source, ts.inv, ts.ray_limit, &entry)) return false;
+    if (mesh.root_ref == kBvhSentinel) return false;
+    ts.nodes = mesh.nodes;
+    ts.tris = mesh.tris;
+    ts.cur = mesh.root_ref;
+    ts.tbest = f32_inf();
+    ts.best_slot = 0u;
+    ts.best_orig = 0xFFFFFFFFu;
+    ts.found = 0u;
     st.sp = 0;
-    int32_t cur = mesh.root_ref;
-    while (cur != kBvhSentinel) {
-        while (cur >= 0 && cur != kBvhSentinel) {
-            const float4* q = reinterpret_cast<const float4*>(mesh.nodes + cur);
-            float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
-            float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
-            float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
-            int32_t left = __float_as_int(n3.x), right = __float_as_int(n3.y);
-            float limit = fminf(tbest, ray_limit);
-            float tl = box_entry(lmin, lmax, ray.source, inv, limit);
-            float tr = box_entry(rmin, rmax, ray.source, inv, limit);
-            bool hl = tl != f32_inf(), hr = tr != f32_inf();
-            if (hl && hr) {
-                bool left_first = tl <= tr;
-                int32_t nearc = left_first ? left : right;
-                int32_t farc = left_first ? right : left;
-                st.push(farc);
-                cur = nearc;
-            } else if (hl) {
-                cur = left;
-            } else if (hr) {
-                cur = right;
-            } else {
-                cur = st.pop();
-            }
-        }
-        if (cur == kBvhSentinel) break;
-        {
-            uint32_t ref = (uint32_t)(~cur);
-            uint32_t first = ref >> 3, count = (ref & 7u) + 1u;
-            for (uint32_t k = 0; k < count; k++) {
-                LeafTri tri = load_tri(mesh.tris + first + k);
-                float t;
-                if (triangle_hit(ld3(tri.v0), ld3(tri.v1), ld3(tri.v2), ray, &t)) {
-                    if (t < tbest || (found && t == tbest && tri.orig_index < best_orig)) {
-                        tbest = t;
-                        best_orig = tri.orig_index;
-                        best_slot = first + k;
-                        found = true;
-                    }
-                }
-            }
-            cur = st.pop();
-        }
-    }
-    *best_t = tbest;
-    *slot = best_slot;
-    *orig = best_orig;
-    return found;
+    return true;
 }
 
+// One inner node: test both children, descend into the nearer, defer the other.
+__device__ __forceinline__ void trav_inner(TravState& ts, const Ray& ray, TravStack& st) {
+    const float4* q = reinterpret_cast<const float4*>(ts.nodes + ts.cur);
+    float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
+    float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
+    float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
+    int32_t left = __float_as_int(n3.x), right = __float_as_int(n3.y);
+    float limit = fminf(ts.tbest, ts.ray_limit);
+    float tl, tr;
+    bool hl = box_test(lmin, lmax, ray.source, ts.inv, limit, &tl);
+    bool hr = box_test(rmin, rmax, ray.source, ts.inv, limit, &tr);
+    if (hl && hr) {
+        bool left_first = tl <= tr;
+        st.push(left_first ? right : left);
+        ts.cur = left_first ? left : right;
+    } else if (hl) {
+        ts.cur = left;
+    } else if (hr) {
+        ts.cur = right;
+    } else {
+        ts.cur = st.pop();
+    }
+}
+
+// One leaf: the reference's triangle test on each of its triangles.
+__device__ __forceinline__ void trav_leaf(TravState& ts, const Ray& ray, TravStack& st) {
+    uint32_t ref = (uint32_t)(~ts.cur);
+    uint32_t first = ref >> 3, count = (ref & 7u) + 1u;
+    for (uint32_t k = 0; k < count; k++) {
+        LeafTri tri = load_tri(ts.tris + first + k);
+        float t;
+        if (triangle_hit(ld3(tri.v0), ld3(tri.v1), ld3(tri.v2), ray, &t)) {
+            if (t < ts.tbest || (ts.found && t == ts.tbest && tri.orig_index < ts.best_orig)) {
+                ts.tbest = t;
+                ts.best_orig = tri.orig_index;
+                ts.best_slot = first + k;
+                ts.found = 1u;
+            }
+        }
+    }
+    ts.cur = st.pop();
+}
+
+__device__ __forceinline__ bool trav_is_inner(const TravState& ts) { return ts.cur >= 0 && ts.cur != kBvhSentinel; }
+__device__ __forceinline__ bool trav_done(const TravState& ts) { return ts.cur == kBvhSentinel; }
+
 // mesh/mod.rs:53-65 literally: every triangle, strict <, first wins.
-__device__ __forceinline__ bool mesh_closest_linear(const DMesh& mesh, const Ray& ray, float* best_t, uint32_t* slot,
-                                                    uint32_t* orig) {
+__device__ __forceinline__ bool mesh_closest_linear(const DMesh& mesh, const Ray& ray, float* best_t, uint32_t* slot) {
     float tbest = f32_inf();
     uint32_t best = 0u;
     bool found = false;
@@ -418,18 +416,13 @@ __device__ __forceinline__ bool mesh_closest_linear(const DMesh& mesh, const Ray
     }
     *best_t = tbest;
     *slot = best;
-    *orig = best;
     return found;
 }
 
-// hierarchy/mesh.rs:61-66 + mesh/mod.rs:53-65
-__device__ __forceinline__ void mesh_trace(const DScene& sc, const DNode& n, uint32_t node_index, const Ray& ray,
-                                           bool brute, TravStack& st, Hit* out) {
-    const DMesh& mesh = sc.meshes[n.mesh_id];
-    float t;
-    uint32_t slot, orig;
-    bool found = brute ? mesh_closest_linear(mesh, ray, &t, &slot, &orig)
-                       : mesh_closest_bvh(mesh, ray, st, &t, &slot, &orig);
+// The RayTraceResult of a mesh node (hierarchy/mesh.rs:61-66) once the closest
+// triangle is known: `tri` is the winning triangle's record, `orig` its index.
+__device__ __forceinline__ void mesh_result(const DMesh& mesh, const DNode& n, uint32_t node_index, const Ray& ray,
+                                            bool found, float t, const LeafTri* tri, uint32_t orig, Hit* out) {
     out->hit = found ? 1u : 0u;
     out->hit_inside = 0u;
     out->t = found ? t : f32_inf(); // the reference returns its running t = +inf on a miss
@@ -437,9 +430,9 @@ __device__ __forceinline__ void mesh_trace(const DScene& sc, const DNode& n, uin
     out->node_index = node_index;
     out->tri_index = found ? orig : 0xFFFFFFFFu;
     if (found) {
-        LeafTri tri = load_tri((brute ? mesh.tris_orig : mesh.tris) + slot);
+        LeafTri tr = load_tri(tri);
         ShadeTri sh = mesh.shade[orig];
-        triangle_finish(tri, sh, ray, t, out);
+        triangle_finish(tr, sh, ray, t, out);
     }
 }
 
@@ -451,75 +444,143 @@ __device__ __forceinline__ void mesh_trace(const DScene& sc, const DNode& n, uin
 //   transform (transform.rs:45-66): child sees apply_transform(ray, M^-1); a hit
 //     comes back as point = M*point', t = |point - ray.source|, normal = N*normal';
 //   kd_tree: its child.
-__device__ __forceinline__ void scene_trace(const DScene& sc, Ray ray, bool brute, TravStack& st, Hit* result) {
-    // The saved state of the open internal nodes (outer ray of a transform, running
-    // best of an enclosing collection) lives in the lane's spill column, indexed by
-    // nesting depth.
-    Hit best;
-    best.hit = 0u;
-    best.hit_inside = 0u;
-    best.t = f32_inf();
-    best.material_id = 0u;
-    best.node_index = 0xFFFFFFFFu;
-    best.tri_index = 0xFFFFFFFFu;
-    best.point = mk3(0, 0, 0);
-    best.normal = mk3(0, 0, 0);
-    best.uv = mk2(0, 0);
-    Hit cur = best;
-    cur.t = 0.0f;
-    uint32_t i = 0;
-    uint32_t open = 0xFFFFFFFFu; // innermost open collection / transform
-    int depth = 0;
+// The walk is resumable: at a mesh node whose BVH has to be searched it returns
+// kWalkMesh with the search set up in `ts`; the caller runs the search (possibly
+// interleaved with other lanes' work), stores the node's result in `cur` and
+// calls walk() again with resume = true.  The saved state of the open internal
+// nodes (outer ray of a transform, running best of an enclosing collection)
+// lives in the lane's spill column, indexed by nesting depth.
+struct WalkState {
+    Ray ray;       // the ray in the space of node i
+    Hit best;      // running best of the innermost open collection
+    uint32_t i;    // node to evaluate next
+    uint32_t open; // innermost open collection / transform, or 0xFFFFFFFF
+    int depth;     // number of open collections / transforms
+};
+constexpr int kWalkDone = 0, kWalkMesh = 1;
+
+__device__ __forceinline__ void walk_begin(WalkState& w, const Ray& ray) {
+    w.ray = ray;
+    w.best.hit = 0u;
+    w.best.hit_inside = 0u;
+    w.best.t = f32_inf();
+    w.best.material_id = 0u;
+    w.best.node_index = 0xFFFFFFFFu;
+    w.best.tri_index = 0xFFFFFFFFu;
+    w.best.point = mk3(0, 0, 0);
+    w.best.normal = mk3(0, 0, 0);
+    w.best.uv = mk2(0, 0);
+    w.i = 0u;
+    w.open = 0xFFFFFFFFu;
+    w.depth = 0;
+}
+
+__device__ __forceinline__ void walk_deliver(const DScene& sc, WalkState& w, const Hit& cur) {
+    if (w.open != 0xFFFFFFFFu && sc.nodes[w.open].type == 0u && cur.hit && cur.t < w.best.t) w.best = cur;
+}
+
+__device__ __forceinline__ int walk(const DScene& sc, WalkState& w, Hit& cur, bool resume, bool brute, TravStack& st,
+                                    TravState& ts) {
     const uint32_t n = sc.node_count;
+    if (resume) {
+        w.i++;
+        walk_deliver(sc, w, cur);
+    }
     for (;;) {
-        while (open != 0xFFFFFFFFu && i == sc.nodes[open].end) {
-            const DNode& on = sc.nodes[open];
-            depth--;
+        while (w.open != 0xFFFFFFFFu && w.i == sc.nodes[w.open].end) {
+            const DNode& on = sc.nodes[w.open];
+            w.depth--;
             if (on.type == 0u) {
-                cur = best;
-                if (depth > 0) best = spill_load_hit(st, depth);
+                cur = w.best;
+                if (w.depth > 0) w.best = spill_load_hit(st, w.depth);
             } else {
-                ray = spill_load_ray(st, depth);
+                w.ray = spill_load_ray(st, w.depth);
                 if (cur.hit) {
                     V3 point = mul_point(on.matrix, cur.point);
-                    cur.t = length(point - ray.source);
+                    cur.t = length(point - w.ray.source);
                     cur.point = point;
                     cur.normal = mul(on.normal_matrix, cur.normal);
                 }
             }
-            open = on.parent;
-            if (open != 0xFFFFFFFFu && sc.nodes[open].type == 0u && cur.hit && cur.t < best.t) best = cur;
+            w.open = on.parent;
+            walk_deliver(sc, w, cur);
         }
-        if (i >= n) break;
-        const DNode& nd = sc.nodes[i];
+        if (w.i >= n) return kWalkDone;
+        const DNode& nd = sc.nodes[w.i];
         uint32_t type = nd.type;
         if (type == 0u) { // collection
-            if (depth > 0) spill_store_hit(st, depth, best);
-            depth++;
-            open = i;
-            best.hit = 0u;
-            best.hit_inside = 0u;
-            best.t = f32_inf();
-            i++;
+            if (w.depth > 0) spill_store_hit(st, w.depth, w.best);
+            w.depth++;
+            w.open = w.i;
+            w.best.hit = 0u;
+            w.best.hit_inside = 0u;
+            w.best.t = f32_inf();
+            w.i++;
             continue;
         }
         if (type == 1u) { // transform
-            spill_store_ray(st, depth, ray);
-            depth++;
-            open = i;
-            ray = apply_transform(ray, nd.matrix_inverse, nd.inverse_normal_matrix);
-            i++;
+            spill_store_ray(st, w.depth, w.ray);
+            w.depth++;
+            w.open = w.i;
+            w.ray = apply_transform(w.ray, nd.matrix_inverse, nd.inverse_normal_matrix);
+            w.i++;
             continue;
         }
         if (type == 5u) { // kd_tree
-            i++;
+            w.i++;
             continue;
         }
-        if (type == 2u) mesh_trace(sc, nd, i, ray, brute, st, &cur);
-        else if (type == 3u) sphere_trace(nd, i, ray, &cur);
-        else plane_trace(nd, i, ray, &cur);
-        i++;
-        if (open != 0xFFFFFFFFu && sc.nodes[open].type == 0u && cur.hit && cur.t < best.t) best = cur;
+        if (type == 2u) {
+            const DMesh& mesh = sc.meshes[nd.mesh_id];
+            if (brute) {
+                float t;
+                uint32_t slot;
+                bool found = mesh_closest_linear(mesh, w.ray, &t, &slot);
+                mesh_result(mesh, nd, w.i, w.ray, found, t, mesh.tris_orig + slot, slot, &cur);
+            } else {
+                if (trav_begin(mesh, w.ray, st, ts)) return kWalkMesh;
+                mesh_result(mesh, nd, w.i, w.ray, false, 0.0f, nullptr, 0u, &cur);
+            }
+        } else if (type == 3u) {
+            sphere_trace(nd, w.i, w.ray, &cur);
+        } else {
+            plane_trace(nd, w.i, w.ray, &cur);
+        }
+        w.i++;
+        walk_deliver(sc, w, cur);
+    }
+}
+
+// The result of the mesh node the walk stopped at, from a finished search.
+__device__ __forceinline__ void walk_mesh_result(const DScene& sc, const WalkState& w, const TravState& ts, Hit* cur) {
+    const DNode& nd = sc.nodes[w.i];
+    const DMesh& mesh = sc.meshes[nd.mesh_id];
+    mesh_result(mesh, nd, w.i, w.ray, ts.found != 0u, ts.tbest, ts.tris + ts.best_slot, ts.best_orig, cur);
+}
+
+// scene.hierarchy.trace_ray for one ray, every search run to its end in place.
+__device__ __forceinline__ void scene_trace(const DScene& sc, Ray ray, bool brute, TravStack& st, Hit* result) {
+    WalkState w;
+    TravState ts;
+    Hit cur;
+    cur.hit = 0u;
+    cur.hit_inside = 0u;
+    cur.t = 0.0f;
+    cur.material_id = 0u;
+    cur.node_index = 0xFFFFFFFFu;
+    cur.tri_index = 0xFFFFFFFFu;
+    cur.point = mk3(0, 0, 0);
+    cur.normal = mk3(0, 0, 0);
+    cur.uv = mk2(0, 0);
+    walk_begin(w, ray);
+    bool resume = false;
+    while (walk(sc, w, cur, resume, brute, st, ts) == kWalkMesh) {
+        while (!trav_done(ts)) {
+            while (trav_is_inner(ts)) trav_inner(ts, w.ray, st);
+            if (!trav_done(ts)) trav_leaf(ts, w.ray, st);
+        }
+        walk_mesh_result(sc, w, ts, &cur);
+        resume = true;
     }
     *result = cur;
 }

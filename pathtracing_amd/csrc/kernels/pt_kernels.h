@@ -15,11 +15,15 @@ namespace ptk {
 // float4 arrays, so every lane's load is 16 bytes and a wave's is 1 KiB):
 //   a = (source.xyz, ray.min)   b = (direction.xyz, bits(path id))
 //   c = (multiplier.rgb, bits(random-stream draw counter))
+// A queue is cut into one region per wave of the persistent grid (region w starts
+// at w * queue_region_capacity()); wave_counts[q][w] is the number of records in
+// region w of queue q.
 struct Workspace {
     float4* queue[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    uint32_t* wave_counts[2] = {nullptr, nullptr};
     float* contrib = nullptr;    // 3 floats per path of the batch: its final colour
-    uint32_t* counters = nullptr; // kMaxDepthCounters queue lengths
-    uint64_t capacity_paths = 0;
+    uint64_t capacity_paths = 0; // records each queue array holds
+    uint64_t contrib_paths = 0;  // paths the contribution buffer holds
     uint64_t* ray_total = nullptr; // device-side running sum of traced rays
     // Trace kernels run a persistent grid of `persistent_blocks` blocks; `spill`
     // holds one column of spill_dwords() dwords per thread of that grid.
@@ -27,8 +31,10 @@ struct Workspace {
     uint32_t persistent_blocks = 0;
 };
 size_t spill_dwords_per_thread();
+uint32_t segment_blocks_per_cu(); // resident blocks per compute unit the trace kernels are built for
+// Records per wave region for a batch of `paths` path slots on a grid of `waves` waves.
+uint32_t queue_region_capacity(uint64_t paths, uint32_t waves);
 constexpr uint32_t kTraceBlock = 256;
-constexpr uint32_t kMaxDepthCounters = 4096;
 
 struct BatchGeometry {
     uint32_t x0, y0, w, h; // pixel rectangle, camera space

@@ -1,11 +1,11 @@
 // gfx950 kernels of the wavefront path tracer.
 //
 // One batch = some consecutive samples of every pixel of a rectangle.  Per batch:
-//   raygen_kernel        camera rays for every path slot -> queue 0
-//   bounce_kernel  x D   one path segment per live path: scene trace + material
-//                        sampling; survivors are compacted into the other queue
-//                        (wave ballot + one atomic per wave), finished paths
-//                        store their colour into the contribution buffer
+//   segment_kernel x D   one path segment per live path (the first launch also
+//                        generates the camera rays): scene trace + material
+//                        sampling; survivors go to the wave's region of the other
+//                        queue, finished paths store their colour into the
+//                        contribution buffer
 //   accumulate_kernel    per pixel, adds the batch's contributions in sample order
 // (work_group.rs:26-69 is the per-pixel loop this replaces).
 #include <hip/hip_runtime.h>
@@ -29,20 +29,6 @@ __device__ __forceinline__ void path_slot_to_pixel(const BatchGeometry& g, uint3
     *y = g.y0 + ly;
 }
 
-// Appends the calling lane's record (when `alive`) to a queue; returns its slot.
-__device__ __forceinline__ uint32_t queue_reserve(bool alive, uint32_t* counter) {
-    unsigned long long mask = __ballot(alive);
-    uint32_t lane = __lane_id();
-    uint32_t base = 0;
-    if (mask != 0ull) {
-        uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-        if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-        base = __shfl(base, (int)leader);
-    }
-    unsigned long long below = mask & ((1ull << lane) - 1ull);
-    return base + (uint32_t)__popcll(below);
-}
-
 struct RenderParams {
     DScene scene;
     DCamera cam;
@@ -54,37 +40,6 @@ struct RenderParams {
     uint32_t brute;
 };
 
-__global__ void __launch_bounds__(kBlock) raygen_kernel(RenderParams p, float4* qa, float4* qb, float4* qc,
-                                                        uint32_t* counters, float* contrib) {
-    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    uint64_t total = (uint64_t)p.sample_count * p.geo.npp;
-    bool alive = false;
-    Ray ray;
-    uint32_t rng_counter = 0;
-    if (gid < total) {
-        uint32_t s_local = (uint32_t)(gid / p.geo.npp);
-        uint32_t q = (uint32_t)(gid % p.geo.npp);
-        uint32_t x, y;
-        bool valid;
-        path_slot_to_pixel(p.geo, q, &x, &y, &valid);
-        if (valid) {
-            Rng rng;
-            rng.key = stream_key(p.seed, stream_id(p.sample_first + s_local, (uint64_t)x + (uint64_t)y * p.cam.width));
-            rng.counter = 0;
-            ray = camera_get_ray(p.cam, x, y, rng);
-            rng_counter = rng.counter;
-            alive = true;
-        }
-    }
-    uint32_t slot = queue_reserve(alive, &counters[0]);
-    if (alive) {
-        qa[slot] = make_float4(ray.source.x, ray.source.y, ray.source.z, ray.min);
-        qb[slot] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, __uint_as_float((uint32_t)gid));
-        qc[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng_counter));
-    }
-    (void)contrib;
-}
-
 __device__ __forceinline__ TravStack make_stack(int32_t* lds_stack, uint32_t* spill, uint32_t spill_threads) {
     TravStack st;
     st.lds = &lds_stack[threadIdx.x];
@@ -95,81 +50,213 @@ __device__ __forceinline__ TravStack make_stack(int32_t* lds_stack, uint32_t* sp
     return st;
 }
 
-// Persistent grid: wave w of the launch takes queue chunks w, w + W, w + 2W, ...
-// of 64 consecutive records (W = waves in the grid), so neighbouring chunks --
-// neighbouring pixels on the first segment -- are in flight together.
-__global__ void __launch_bounds__(kBlock, 4) bounce_kernel(RenderParams p, uint32_t depth, const float4* __restrict__ ia,
-                                                        const float4* __restrict__ ib, const float4* __restrict__ ic,
-                                                        float4* oa, float4* ob, float4* oc, uint32_t* counters,
-                                                        float* contrib, unsigned long long* ray_total,
-                                                        uint32_t* spill, uint32_t spill_threads) {
+#ifndef PT_SEGMENT_OCCUPANCY
+#define PT_SEGMENT_OCCUPANCY 4 // waves per SIMD the segment kernel is compiled for = resident 256-thread blocks per CU
+#endif
+#ifndef PT_REFILL
+#define PT_REFILL 16
+#endif
+uint32_t segment_blocks_per_cu() { return PT_SEGMENT_OCCUPANCY; }
+constexpr uint32_t kRefill = PT_REFILL; // go back for new rays once this many lanes of a wave have finished their search
+
+// One path segment (work_group.rs:29-47) for every live path of the batch.
+//
+// Persistent grid; every wave owns a fixed region of the ray queues (region w =
+// records [w * cap, w * cap + count_w)), reads its rays from the input region and
+// appends surviving paths to its output region, so queues need no atomics and no
+// global compaction pass.  On the first segment (FIRST) there is no input queue:
+// the wave generates camera rays for path slots taken in 64-slot chunks w, w + W,
+// w + 2W, ... (W = waves in the grid), which spreads every wave's share over the
+// whole frame and keeps the regions' loads balanced in later segments.
+//
+// Inside a wave, lanes do not wait for the slowest ray: each lane runs a small
+// state machine (idle -> walking the scene graph -> searching a mesh BVH ->
+// walking -> shading -> idle) and the wave refills idle lanes from its region
+// whenever kRefill searches have finished.  BVH search lengths vary by an order
+// of magnitude between neighbouring rays, so this is what keeps lanes busy.
+template <bool FIRST>
+__global__ void __launch_bounds__(kBlock, PT_SEGMENT_OCCUPANCY)
+segment_kernel(RenderParams p, uint32_t depth, uint32_t cap, const float4* __restrict__ ia, const float4* __restrict__ ib,
+               const float4* __restrict__ ic, float4* oa, float4* ob, float4* oc, const uint32_t* __restrict__ counts_in,
+               uint32_t* counts_out, float* contrib, unsigned long long* ray_total, uint32_t* spill,
+               uint32_t spill_threads) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
-    const uint32_t count = counters[depth];
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
-    if (tid == 0) atomicAdd(ray_total, (unsigned long long)count);
-    const uint32_t grid_threads = gridDim.x * kBlock;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+    const uint32_t waves = (gridDim.x * kBlock) >> 6;
+    const uint64_t total = (uint64_t)p.sample_count * p.geo.npp;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const size_t region = (size_t)wave * cap;
+
+    uint32_t nin; // records this wave will take
+    if (FIRST) {
+        uint32_t chunks_total = (uint32_t)((total + 63u) >> 6);
+        nin = wave < chunks_total ? ((chunks_total - wave + waves - 1u) / waves) * 64u : 0u;
+    } else {
+        nin = counts_in[wave];
+    }
+    uint32_t next = 0, out_pos = 0, traced = 0;
+
     TravStack st = make_stack(lds_stack, spill, spill_threads);
-    for (uint32_t base = tid & ~63u; base < count; base += grid_threads) {
-        const uint32_t gid = base + (tid & 63u);
-        bool active = gid < count;
-        bool next_alive = false;
-        Ray nray;
-        V3 nmult = mk3(0, 0, 0);
-        uint32_t path = 0, rng_counter = 0;
-        if (active) {
-            float4 a = ia[gid], b = ib[gid], c = ic[gid];
-            Ray ray;
-            ray.source = mk3(a.x, a.y, a.z);
-            ray.min = a.w;
-            ray.direction = mk3(b.x, b.y, b.z);
-            ray.max = kF32Max;
-            path = __float_as_uint(b.w);
-            V3 mult = mk3(c.x, c.y, c.z);
-            rng_counter = __float_as_uint(c.w);
+    WalkState w;
+    TravState ts;
+    Hit cur;
+    cur.hit = 0u;
+    cur.hit_inside = 0u;
+    cur.t = 0.0f;
+    cur.material_id = 0u;
+    cur.node_index = 0xFFFFFFFFu;
+    cur.tri_index = 0xFFFFFFFFu;
+    cur.point = mk3(0, 0, 0);
+    cur.normal = mk3(0, 0, 0);
+    cur.uv = mk2(0, 0);
+    ts.cur = kBvhSentinel;
+    uint32_t phase = 0; // 0 idle, 1 searching a mesh, 2 walking the scene graph
+    bool fresh = false;
+    uint32_t path = 0, rng_counter = 0;
+    V3 mult = mk3(0, 0, 0);
+    const bool brute = p.brute != 0u;
 
-            Hit hit;
-            scene_trace(p.scene, ray, p.brute != 0u, st, &hit);
-
-            V3 color = mk3(0, 0, 0);
-            bool finished = true;
-            if (hit.hit) {
-                uint32_t s_local = path / p.geo.npp, q = path % p.geo.npp;
-                uint32_t x, y;
-                bool valid;
-                path_slot_to_pixel(p.geo, q, &x, &y, &valid);
-                Rng rng;
-                rng.key = stream_key(p.seed, stream_id(p.sample_first + s_local, (uint64_t)x + (uint64_t)y * p.cam.width));
-                rng.counter = rng_counter;
-                V3 av, dir;
-                bool is_color =
-                    material_get_color(p.scene.materials[hit.material_id], ray.direction, hit, rng, &av, &dir);
-                rng_counter = rng.counter;
-                if (is_color) {
-                    color = mult * av; // work_group.rs:39-41
-                } else if (depth + 1u < p.trace_depth) {
-                    // work_group.rs:42-46
-                    nray.source = hit.point + dir * kEpsilon;
-                    nray.direction = dir;
-                    nray.min = kEpsilon;
-                    nray.max = kF32Max;
-                    nmult = mult * av;
-                    finished = false;
-                    next_alive = true;
+    for (;;) {
+        // ---- hand new rays to idle lanes
+        unsigned long long idle_mask = __ballot(phase == 0u);
+        uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+        uint32_t avail = nin - next;
+        if (n_idle != 0u && avail != 0u) {
+            uint32_t rank = (uint32_t)__popcll(idle_mask & lane_lt);
+            if (phase == 0u && rank < avail) {
+                uint32_t v = next + rank;
+                Ray ray;
+                bool have = false;
+                if (FIRST) {
+                    uint64_t slot = ((uint64_t)(v >> 6) * waves + wave) * 64u + (v & 63u);
+                    if (slot < total) {
+                        uint32_t s_local = (uint32_t)(slot / p.geo.npp);
+                        uint32_t q = (uint32_t)(slot % p.geo.npp);
+                        uint32_t x, y;
+                        bool valid;
+                        path_slot_to_pixel(p.geo, q, &x, &y, &valid);
+                        if (valid) {
+                            Rng rng;
+                            rng.key = stream_key(p.seed, stream_id(p.sample_first + s_local,
+                                                                   (uint64_t)x + (uint64_t)y * p.cam.width));
+                            rng.counter = 0;
+                            ray = camera_get_ray(p.cam, x, y, rng);
+                            rng_counter = rng.counter;
+                            path = (uint32_t)slot;
+                            mult = mk3(1.0f, 1.0f, 1.0f);
+                            have = true;
+                        }
+                    }
+                } else {
+                    float4 a = ia[region + v], b = ib[region + v], c = ic[region + v];
+                    ray.source = mk3(a.x, a.y, a.z);
+                    ray.min = a.w;
+                    ray.direction = mk3(b.x, b.y, b.z);
+                    ray.max = kF32Max;
+                    path = __float_as_uint(b.w);
+                    mult = mk3(c.x, c.y, c.z);
+                    rng_counter = __float_as_uint(c.w);
+                    have = true;
+                }
+                if (have) {
+                    walk_begin(w, ray);
+                    phase = 2u;
+                    fresh = true;
                 }
             }
-            if (finished) {
-                float* dst = contrib + (size_t)path * 3;
-                dst[0] = color.x;
-                dst[1] = color.y;
-                dst[2] = color.z;
+            next += n_idle < avail ? n_idle : avail;
+        }
+
+        // ---- scene-graph walk for new rays and for rays back from a finished search
+        bool emit = false;
+        Ray nray;
+        V3 nmult = mk3(0, 0, 0);
+        if (phase == 2u) {
+            int r = walk(p.scene, w, cur, !fresh, brute, st, ts);
+            fresh = false;
+            if (r == kWalkMesh) {
+                phase = 1u;
+            } else {
+                // the segment's trace is complete: work_group.rs:31-47
+                traced++;
+                phase = 0u;
+                V3 color = mk3(0, 0, 0);
+                bool finished = true;
+                if (cur.hit) {
+                    uint32_t s_local = path / p.geo.npp, q = path % p.geo.npp;
+                    uint32_t x, y;
+                    bool valid;
+                    path_slot_to_pixel(p.geo, q, &x, &y, &valid);
+                    Rng rng;
+                    rng.key = stream_key(p.seed, stream_id(p.sample_first + s_local, (uint64_t)x + (uint64_t)y * p.cam.width));
+                    rng.counter = rng_counter;
+                    V3 av, dir;
+                    bool is_color =
+                        material_get_color(p.scene.materials[cur.material_id], w.ray.direction, cur, rng, &av, &dir);
+                    rng_counter = rng.counter;
+                    if (is_color) {
+                        color = mult * av;
+                    } else if (depth + 1u < p.trace_depth) {
+                        nray.source = cur.point + dir * kEpsilon;
+                        nray.direction = dir;
+                        nray.min = kEpsilon;
+                        nray.max = kF32Max;
+                        nmult = mult * av;
+                        finished = false;
+                        emit = true;
+                    }
+                }
+                if (finished) {
+                    float* dst = contrib + (size_t)path * 3;
+                    dst[0] = color.x;
+                    dst[1] = color.y;
+                    dst[2] = color.z;
+                }
             }
         }
-        uint32_t slot = queue_reserve(next_alive, &counters[depth + 1u]);
-        if (next_alive) {
-            oa[slot] = make_float4(nray.source.x, nray.source.y, nray.source.z, nray.min);
-            ob[slot] = make_float4(nray.direction.x, nray.direction.y, nray.direction.z, __uint_as_float(path));
-            oc[slot] = make_float4(nmult.x, nmult.y, nmult.z, __uint_as_float(rng_counter));
+        // ---- surviving paths go to this wave's region of the output queue
+        unsigned long long emit_mask = __ballot(emit);
+        if (emit_mask != 0ull) {
+            if (emit) {
+                size_t slot = region + out_pos + (uint32_t)__popcll(emit_mask & lane_lt);
+                oa[slot] = make_float4(nray.source.x, nray.source.y, nray.source.z, nray.min);
+                ob[slot] = make_float4(nray.direction.x, nray.direction.y, nray.direction.z, __uint_as_float(path));
+                oc[slot] = make_float4(nmult.x, nmult.y, nmult.z, __uint_as_float(rng_counter));
+            }
+            out_pos += (uint32_t)__popcll(emit_mask);
         }
+
+        // ---- BVH searches
+        unsigned long long search_mask = __ballot(phase == 1u);
+        if (search_mask == 0ull) {
+            if (next >= nin && __ballot(phase != 0u) == 0ull) break;
+            continue;
+        }
+        const uint32_t n_search = (uint32_t)__popcll(search_mask);
+        for (;;) {
+            while (phase == 1u && trav_is_inner(ts)) trav_inner(ts, w.ray, st);
+            if (phase == 1u && !trav_done(ts)) trav_leaf(ts, w.ray, st);
+            unsigned long long unfinished = __ballot(phase == 1u && !trav_done(ts));
+            uint32_t n_unfinished = (uint32_t)__popcll(unfinished);
+            if (n_unfinished == 0u || n_unfinished + kRefill <= n_search) break;
+        }
+        if (phase == 1u && trav_done(ts)) {
+            walk_mesh_result(p.scene, w, ts, &cur);
+            phase = 2u;
+        }
+    }
+    // ---- wave epilogue: queue length of the region, rays traced
+    unsigned long long traced_total = 0;
+    {
+        uint32_t v = traced;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        traced_total = v;
+    }
+    if (lane == 0u) {
+        if (counts_out) counts_out[wave] = out_pos;
+        if (traced_total) atomicAdd(ray_total, traced_total);
     }
 }
 
@@ -288,6 +375,11 @@ __global__ void __launch_bounds__(kBlock) shade_kernel(DScene scene, const PtVec
 // ------------------------------------------------------------------ launchers
 
 size_t spill_dwords_per_thread() { return (size_t)kSpillDwords; }
+uint32_t queue_region_capacity(uint64_t paths, uint32_t waves) {
+    uint64_t chunks = (paths + 63) / 64;
+    uint64_t per_wave = (chunks + waves - 1) / waves;
+    return (uint32_t)(per_wave * 64);
+}
 static_assert(kTraceBlock == (uint32_t)kBlock, "block size mismatch");
 
 static inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
@@ -307,13 +399,11 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
     p.brute = brute ? 1u : 0u;
     uint64_t total = (uint64_t)sample_count * geo.npp;
     if (total == 0 || trace_depth == 0) return hipSuccess;
-    if (total > ws.capacity_paths || total > 0xFFFFFFFFull || trace_depth + 1u > kMaxDepthCounters || !ws.spill)
-        return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(ws.counters, 0, sizeof(uint32_t) * (trace_depth + 1u), stream);
-    if (e != hipSuccess) return e;
-    // slots of pixels outside the rectangle never run a path: their contribution is never read
-    raygen_kernel<<<blocks_for(total), kBlock, 0, stream>>>(p, ws.queue[0][0], ws.queue[0][1], ws.queue[0][2],
-                                                             ws.counters, ws.contrib);
+    if (!ws.spill || ws.persistent_blocks == 0 || total > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    const uint32_t waves = ws.persistent_blocks * (kBlock / 64);
+    const uint32_t cap = queue_region_capacity(total, waves);
+    if ((uint64_t)cap * waves > ws.capacity_paths || total > ws.contrib_paths) return hipErrorInvalidValue;
+    hipError_t e;
     for (uint32_t d = 0; d < trace_depth; d++) {
         int in = d & 1, out = in ^ 1;
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -324,11 +414,17 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
             segment_events->push_back(e1);
             if ((e = hipEventRecord(e0, stream)) != hipSuccess) return e;
         }
-        // the queue cannot be longer than the batch; the kernel reads the real length
-        bounce_kernel<<<std::min(blocks_for(total), ws.persistent_blocks), kBlock, 0, stream>>>(
-            p, d, ws.queue[in][0], ws.queue[in][1], ws.queue[in][2], ws.queue[out][0], ws.queue[out][1],
-            ws.queue[out][2], ws.counters, ws.contrib, reinterpret_cast<unsigned long long*>(ws.ray_total), ws.spill,
-            ws.persistent_blocks * kBlock);
+        uint32_t* counts_out = (d + 1 < trace_depth) ? ws.wave_counts[out] : nullptr;
+        unsigned long long* rt = reinterpret_cast<unsigned long long*>(ws.ray_total);
+        if (d == 0)
+            segment_kernel<true><<<ws.persistent_blocks, kBlock, 0, stream>>>(
+                p, d, cap, nullptr, nullptr, nullptr, ws.queue[out][0], ws.queue[out][1], ws.queue[out][2], nullptr,
+                counts_out, ws.contrib, rt, ws.spill, ws.persistent_blocks * kBlock);
+        else
+            segment_kernel<false><<<ws.persistent_blocks, kBlock, 0, stream>>>(
+                p, d, cap, ws.queue[in][0], ws.queue[in][1], ws.queue[in][2], ws.queue[out][0], ws.queue[out][1],
+                ws.queue[out][2], ws.wave_counts[in], counts_out, ws.contrib, rt, ws.spill,
+                ws.persistent_blocks * kBlock);
         if (segment_events && (e = hipEventRecord(e1, stream)) != hipSuccess) return e;
     }
     accumulate_kernel<<<blocks_for(geo.npp), kBlock, 0, stream>>>(geo, cam.width, sample_count, ws.contrib, d_accum);

@@ -1,6 +1,6 @@
 import sys, time, json, os
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pathtracing_amd as P
 from pathtracing_amd import synth
 out = '/tmp/dragon_probe'
