@@ -67,6 +67,7 @@ struct PtScene {
     ptk::Workspace ws;
     uint64_t bvh_bytes = 0;
     uint32_t node_count = 0;
+    uint32_t mesh_nodes = 0; // mesh nodes in the scene graph = BVH searches one ray can need
     std::vector<uint32_t> mesh_tri_count;
 
     void* dev_alloc(size_t bytes) {
@@ -87,6 +88,17 @@ struct PtScene {
                     (void)hipFree(ws.queue[q][k]);
                     ws.queue[q][k] = nullptr;
                 }
+        for (int q = 0; q < 2; q++)
+            for (int k = 0; k < 3; k++)
+                if (ws.jobs[q][k]) {
+                    (void)hipFree(ws.jobs[q][k]);
+                    ws.jobs[q][k] = nullptr;
+                }
+        for (int k = 0; k < ptk::kMaxDeferred; k++)
+            if (ws.results[k]) {
+                (void)hipFree(ws.results[k]);
+                ws.results[k] = nullptr;
+            }
         if (ws.contrib) (void)hipFree(ws.contrib);
         ws.contrib = nullptr;
         ws.capacity_paths = 0;
@@ -103,8 +115,11 @@ struct PtScene {
         size_t bytes = (size_t)ws.persistent_blocks * ptk::kTraceBlock * ptk::spill_dwords_per_thread() * sizeof(uint32_t);
         hip_check(hipMalloc(reinterpret_cast<void**>(&ws.spill), bytes), "hipMalloc spill");
         size_t waves = (size_t)ws.persistent_blocks * (ptk::kTraceBlock / 64);
-        for (int q = 0; q < 2; q++)
+        for (int q = 0; q < 2; q++) {
             hip_check(hipMalloc(reinterpret_cast<void**>(&ws.wave_counts[q]), waves * sizeof(uint32_t)), "hipMalloc counts");
+            hip_check(hipMalloc(reinterpret_cast<void**>(&ws.job_counts[q]), waves * sizeof(uint32_t)), "hipMalloc counts");
+            hip_check(hipMemset(ws.job_counts[q], 0, waves * sizeof(uint32_t)), "hipMemset");
+        }
         hip_check(hipMalloc(reinterpret_cast<void**>(&ws.ray_total), sizeof(uint64_t)), "hipMalloc ray_total");
     }
     void ensure_workspace(uint64_t paths) {
@@ -116,14 +131,22 @@ struct PtScene {
         for (int q = 0; q < 2; q++)
             for (int k = 0; k < 3; k++)
                 hip_check(hipMalloc(reinterpret_cast<void**>(&ws.queue[q][k]), records * sizeof(float4)), "hipMalloc queue");
+        for (int q = 0; q < 2; q++)
+            for (int k = 0; k < 3; k++)
+                hip_check(hipMalloc(reinterpret_cast<void**>(&ws.jobs[q][k]), records * sizeof(float4)), "hipMalloc jobs");
+        uint32_t result_arrays = std::min<uint32_t>(std::max<uint32_t>(mesh_nodes, 1u), (uint32_t)ptk::kMaxDeferred);
+        for (uint32_t k = 0; k < result_arrays; k++)
+            hip_check(hipMalloc(reinterpret_cast<void**>(&ws.results[k]), records * sizeof(float4)), "hipMalloc results");
         hip_check(hipMalloc(reinterpret_cast<void**>(&ws.contrib), paths * 3 * sizeof(float)), "hipMalloc contrib");
         ws.capacity_paths = records;
         ws.contrib_paths = paths;
     }
     ~PtScene() {
         free_workspace();
-        for (int q = 0; q < 2; q++)
+        for (int q = 0; q < 2; q++) {
             if (ws.wave_counts[q]) (void)hipFree(ws.wave_counts[q]);
+            if (ws.job_counts[q]) (void)hipFree(ws.job_counts[q]);
+        }
         if (ws.ray_total) (void)hipFree(ws.ray_total);
         if (ws.spill) (void)hipFree(ws.spill);
         for (void* p : allocs) (void)hipFree(p);
@@ -369,7 +392,8 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
         for (uint64_t s = 0; s < task->iterations; s += samples_per_batch) {
             uint32_t cnt = (uint32_t)std::min<uint64_t>(samples_per_batch, task->iterations - s);
             hip_check(ptk::render_batch(scene->d, cam, g, o.seed, o.sample_offset + s, cnt, (uint32_t)task->trace_depth,
-                                        brute, scene->ws, d_accum, stream, profile ? &seg_events : nullptr),
+                                        brute, scene->mesh_nodes, scene->ws, d_accum, stream,
+                                        profile ? &seg_events : nullptr),
                       "render_batch");
             paths += (uint64_t)cnt * g.w * g.h;
         }
@@ -431,6 +455,8 @@ PtStatus pt_scene_create(const PtSceneDesc* desc, int device, PtScene** out_scen
         std::vector<ptk::DNode> nodes;
         layout_nodes(*desc, nodes);
         s->node_count = desc->node_count;
+        for (uint32_t i = 0; i < desc->node_count; i++)
+            if (desc->nodes[i].type == PT_NODE_MESH) s->mesh_nodes++;
 
         // a kd_tree node directly above a mesh node offers its .tree blob to that mesh
         std::vector<const PtTreeBlob*> mesh_blob(desc->mesh_count, nullptr);

@@ -21,6 +21,11 @@ namespace ptk {
 struct Workspace {
     float4* queue[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     uint32_t* wave_counts[2] = {nullptr, nullptr};
+    // BVH search requests of the current / previous round and their per-region counts;
+    // results[k] = result of a ray's k-th search of the segment, indexed like a queue
+    float4* jobs[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    uint32_t* job_counts[2] = {nullptr, nullptr};
+    float4* results[4] = {nullptr, nullptr, nullptr, nullptr};
     float* contrib = nullptr;    // 3 floats per path of the batch: its final colour
     uint64_t capacity_paths = 0; // records each queue array holds
     uint64_t contrib_paths = 0;  // paths the contribution buffer holds
@@ -36,6 +41,8 @@ uint32_t segment_blocks_per_cu(); // resident blocks per compute unit the trace 
 uint32_t queue_region_capacity(uint64_t paths, uint32_t waves);
 constexpr uint32_t kTraceBlock = 256;
 
+constexpr int kMaxDeferred = 4; // BVH searches per ray and segment that go through the search kernel
+
 struct BatchGeometry {
     uint32_t x0, y0, w, h; // pixel rectangle, camera space
     uint32_t nbx, nby;     // 8x8 pixel blocks covering it
@@ -49,7 +56,7 @@ struct BatchGeometry {
 // recorded around every path-segment kernel launch and appended to the vector.
 hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeometry& geo, uint64_t seed,
                         uint64_t sample_first, uint32_t sample_count, uint32_t trace_depth, bool brute,
-                        Workspace& ws, float* d_accum, hipStream_t stream,
+                        uint32_t mesh_nodes, Workspace& ws, float* d_accum, hipStream_t stream,
                         std::vector<hipEvent_t>* segment_events);
 
 hipError_t resolve_image(const float* d_accum, uint32_t width, uint32_t height, float scale, float* d_out,

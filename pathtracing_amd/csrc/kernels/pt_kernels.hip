@@ -50,36 +50,51 @@ __device__ __forceinline__ TravStack make_stack(int32_t* lds_stack, uint32_t* sp
     return st;
 }
 
-#ifndef PT_SEGMENT_OCCUPANCY
-#define PT_SEGMENT_OCCUPANCY 4 // waves per SIMD the segment kernel is compiled for = resident 256-thread blocks per CU
+#ifndef PT_SEARCH_OCCUPANCY
+#define PT_SEARCH_OCCUPANCY 8 // waves per SIMD the BVH search kernel is compiled for
 #endif
 #ifndef PT_REFILL
 #define PT_REFILL 16
 #endif
-uint32_t segment_blocks_per_cu() { return PT_SEGMENT_OCCUPANCY; }
-constexpr uint32_t kRefill = PT_REFILL; // go back for new rays once this many lanes of a wave have finished their search
+constexpr uint32_t kRefill = PT_REFILL; // refill a wave once this many of its lanes have finished their search
+constexpr uint32_t kGridBlocksPerCu = PT_SEARCH_OCCUPANCY;
+uint32_t segment_blocks_per_cu() { return kGridBlocksPerCu; }
 
-// One path segment (work_group.rs:29-47) for every live path of the batch.
-//
-// Persistent grid; every wave owns a fixed region of the ray queues (region w =
-// records [w * cap, w * cap + count_w)), reads its rays from the input region and
-// appends surviving paths to its output region, so queues need no atomics and no
-// global compaction pass.  On the first segment (FIRST) there is no input queue:
-// the wave generates camera rays for path slots taken in 64-slot chunks w, w + W,
-// w + 2W, ... (W = waves in the grid), which spreads every wave's share over the
-// whole frame and keeps the regions' loads balanced in later segments.
-//
-// Inside a wave, lanes do not wait for the slowest ray: each lane runs a small
-// state machine (idle -> walking the scene graph -> searching a mesh BVH ->
-// walking -> shading -> idle) and the wave refills idle lanes from its region
-// whenever kRefill searches have finished.  BVH search lengths vary by an order
-// of magnitude between neighbouring rays, so this is what keeps lanes busy.
+// Device pointers of one path segment.  Every array is cut into `regions` regions
+// of `cap` records; region r is owned by one wave per kernel (wave w of a launch
+// takes regions w, w + W, ...), so nothing here needs atomics:
+//   rays      this segment's rays            (source,min) (direction,path id) (multiplier,draw counter)
+//   next      rays of the next segment, appended per region, lengths in next_counts
+//   jobs      BVH searches requested by the walk kernel of this round
+//             (object-space source,min) (direction,max) (ray index, mesh id, search number, -)
+//   prev_jobs the previous round's requests = the rays the walk kernel of this round continues
+//   res[k]    result of a ray's k-th search, indexed like `rays`: (t, found, leaf slot, triangle index)
+struct SegmentBuffers {
+    float4 *ray_a, *ray_b, *ray_c;
+    const uint32_t* ray_counts;
+    float4 *next_a, *next_b, *next_c;
+    uint32_t* next_counts;
+    float4 *job_a, *job_b, *job_c;
+    uint32_t* job_counts;
+    const float4* prev_job_c;
+    const uint32_t* prev_job_counts;
+    float4* res[kMaxDeferred];
+};
+
+// ---------------------------------------------------------------- walk kernel
+// Everything of a path segment (work_group.rs:29-47) except the BVH searches:
+// camera ray (first segment), scene-graph walk, material sampling, queueing of
+// the next segment's ray or the path's final colour.  A ray whose walk reaches a
+// mesh whose BVH must be searched is parked: the search is written as a job for
+// search_kernel and the ray is walked again from the start in the next round,
+// this time with the search's result at hand (the walk is deterministic, so the
+// second walk repeats the first bit for bit; re-walking a handful of cheap nodes
+// costs less than saving and restoring the walk's state).  `defer` = false (last
+// round) or more than kMaxDeferred searches on one ray: the search runs in place.
 template <bool FIRST>
-__global__ void __launch_bounds__(kBlock, PT_SEGMENT_OCCUPANCY)
-segment_kernel(RenderParams p, uint32_t depth, uint32_t cap, const float4* __restrict__ ia, const float4* __restrict__ ib,
-               const float4* __restrict__ ic, float4* oa, float4* ob, float4* oc, const uint32_t* __restrict__ counts_in,
-               uint32_t* counts_out, float* contrib, unsigned long long* ray_total, uint32_t* spill,
-               uint32_t spill_threads) {
+__global__ void __launch_bounds__(kBlock, 4)
+walk_kernel(RenderParams p, uint32_t depth, uint32_t round, uint32_t defer, SegmentBuffers b, uint32_t cap,
+            uint32_t regions, float* contrib, unsigned long long* ray_total, uint32_t* spill, uint32_t spill_threads) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -87,50 +102,35 @@ segment_kernel(RenderParams p, uint32_t depth, uint32_t cap, const float4* __res
     const uint32_t waves = (gridDim.x * kBlock) >> 6;
     const uint64_t total = (uint64_t)p.sample_count * p.geo.npp;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    const size_t region = (size_t)wave * cap;
-
-    uint32_t nin; // records this wave will take
-    if (FIRST) {
-        uint32_t chunks_total = (uint32_t)((total + 63u) >> 6);
-        nin = wave < chunks_total ? ((chunks_total - wave + waves - 1u) / waves) * 64u : 0u;
-    } else {
-        nin = counts_in[wave];
-    }
-    uint32_t next = 0, out_pos = 0, traced = 0;
-
-    TravStack st = make_stack(lds_stack, spill, spill_threads);
-    WalkState w;
-    TravState ts;
-    Hit cur;
-    cur.hit = 0u;
-    cur.hit_inside = 0u;
-    cur.t = 0.0f;
-    cur.material_id = 0u;
-    cur.node_index = 0xFFFFFFFFu;
-    cur.tri_index = 0xFFFFFFFFu;
-    cur.point = mk3(0, 0, 0);
-    cur.normal = mk3(0, 0, 0);
-    cur.uv = mk2(0, 0);
-    ts.cur = kBvhSentinel;
-    uint32_t phase = 0; // 0 idle, 1 searching a mesh, 2 walking the scene graph
-    bool fresh = false;
-    uint32_t path = 0, rng_counter = 0;
-    V3 mult = mk3(0, 0, 0);
     const bool brute = p.brute != 0u;
+    TravStack st = make_stack(lds_stack, spill, spill_threads);
+    uint32_t traced = 0;
 
-    for (;;) {
-        // ---- hand new rays to idle lanes
-        unsigned long long idle_mask = __ballot(phase == 0u);
-        uint32_t n_idle = (uint32_t)__popcll(idle_mask);
-        uint32_t avail = nin - next;
-        if (n_idle != 0u && avail != 0u) {
-            uint32_t rank = (uint32_t)__popcll(idle_mask & lane_lt);
-            if (phase == 0u && rank < avail) {
-                uint32_t v = next + rank;
-                Ray ray;
-                bool have = false;
-                if (FIRST) {
-                    uint64_t slot = ((uint64_t)(v >> 6) * waves + wave) * 64u + (v & 63u);
+    for (uint32_t r = wave; r < regions; r += waves) {
+        const size_t base = (size_t)r * cap;
+        uint32_t n_items;
+        if (round > 0u) {
+            n_items = b.prev_job_counts[r];
+        } else if (FIRST) {
+            uint32_t chunks_total = (uint32_t)((total + 63u) >> 6);
+            n_items = r < chunks_total ? ((chunks_total - r + regions - 1u) / regions) * 64u : 0u;
+        } else {
+            n_items = b.ray_counts[r];
+        }
+        uint32_t out_pos = round > 0u ? b.next_counts[r] : 0u;
+        uint32_t job_pos = 0u;
+        for (uint32_t first = 0; first < n_items; first += 64u) {
+            const uint32_t item = first + lane;
+            bool have = item < n_items;
+            uint32_t v = item;
+            if (have && round > 0u) v = __float_as_uint(b.prev_job_c[base + item].x);
+            Ray ray;
+            uint32_t path = 0, rng_counter = 0;
+            V3 mult = mk3(1.0f, 1.0f, 1.0f);
+            if (have) {
+                if (FIRST && round == 0u) {
+                    uint64_t slot = ((uint64_t)(v >> 6) * regions + r) * 64u + (v & 63u);
+                    have = false;
                     if (slot < total) {
                         uint32_t s_local = (uint32_t)(slot / p.geo.npp);
                         uint32_t q = (uint32_t)(slot % p.geo.npp);
@@ -145,118 +145,223 @@ segment_kernel(RenderParams p, uint32_t depth, uint32_t cap, const float4* __res
                             ray = camera_get_ray(p.cam, x, y, rng);
                             rng_counter = rng.counter;
                             path = (uint32_t)slot;
-                            mult = mk3(1.0f, 1.0f, 1.0f);
                             have = true;
                         }
                     }
                 } else {
-                    float4 a = ia[region + v], b = ib[region + v], c = ic[region + v];
-                    ray.source = mk3(a.x, a.y, a.z);
-                    ray.min = a.w;
-                    ray.direction = mk3(b.x, b.y, b.z);
+                    float4 ra = b.ray_a[base + v], rb = b.ray_b[base + v], rc = b.ray_c[base + v];
+                    ray.source = mk3(ra.x, ra.y, ra.z);
+                    ray.min = ra.w;
+                    ray.direction = mk3(rb.x, rb.y, rb.z);
                     ray.max = kF32Max;
-                    path = __float_as_uint(b.w);
-                    mult = mk3(c.x, c.y, c.z);
-                    rng_counter = __float_as_uint(c.w);
-                    have = true;
-                }
-                if (have) {
-                    walk_begin(w, ray);
-                    phase = 2u;
-                    fresh = true;
+                    path = __float_as_uint(rb.w);
+                    mult = mk3(rc.x, rc.y, rc.z);
+                    rng_counter = __float_as_uint(rc.w);
                 }
             }
-            next += n_idle < avail ? n_idle : avail;
-        }
-
-        // ---- scene-graph walk for new rays and for rays back from a finished search
-        bool emit = false;
-        Ray nray;
-        V3 nmult = mk3(0, 0, 0);
-        if (phase == 2u) {
-            int r = walk(p.scene, w, cur, !fresh, brute, st, ts);
-            fresh = false;
-            if (r == kWalkMesh) {
-                phase = 1u;
-            } else {
-                // the segment's trace is complete: work_group.rs:31-47
-                traced++;
-                phase = 0u;
-                V3 color = mk3(0, 0, 0);
-                bool finished = true;
-                if (cur.hit) {
-                    uint32_t s_local = path / p.geo.npp, q = path % p.geo.npp;
-                    uint32_t x, y;
-                    bool valid;
-                    path_slot_to_pixel(p.geo, q, &x, &y, &valid);
-                    Rng rng;
-                    rng.key = stream_key(p.seed, stream_id(p.sample_first + s_local, (uint64_t)x + (uint64_t)y * p.cam.width));
-                    rng.counter = rng_counter;
-                    V3 av, dir;
-                    bool is_color =
-                        material_get_color(p.scene.materials[cur.material_id], w.ray.direction, cur, rng, &av, &dir);
-                    rng_counter = rng.counter;
-                    if (is_color) {
-                        color = mult * av;
-                    } else if (depth + 1u < p.trace_depth) {
-                        nray.source = cur.point + dir * kEpsilon;
-                        nray.direction = dir;
-                        nray.min = kEpsilon;
-                        nray.max = kF32Max;
-                        nmult = mult * av;
-                        finished = false;
-                        emit = true;
+            bool emit = false, park = false;
+            Ray nray;
+            V3 nmult = mk3(0, 0, 0);
+            TravState ts;
+            WalkState w;
+            uint32_t searches = 0; // BVH searches met so far on this walk
+            if (have) {
+                Hit cur;
+                cur.hit = 0u;
+                cur.hit_inside = 0u;
+                cur.t = 0.0f;
+                cur.material_id = 0u;
+                cur.node_index = 0xFFFFFFFFu;
+                cur.tri_index = 0xFFFFFFFFu;
+                cur.point = mk3(0, 0, 0);
+                cur.normal = mk3(0, 0, 0);
+                cur.uv = mk2(0, 0);
+                walk_begin(w, ray);
+                bool resume = false;
+                while (walk(p.scene, w, cur, resume, brute, st, ts) == kWalkMesh) {
+                    if (searches < round && searches < (uint32_t)kMaxDeferred) {
+                        // searched in an earlier round
+                        float4 res = b.res[searches][base + v];
+                        ts.tbest = res.x;
+                        ts.found = __float_as_uint(res.y);
+                        ts.best_slot = __float_as_uint(res.z);
+                        ts.best_orig = __float_as_uint(res.w);
+                    } else if (defer != 0u && searches < (uint32_t)kMaxDeferred) {
+                        park = true;
+                        break;
+                    } else {
+                        while (!trav_done(ts)) {
+                            while (trav_is_inner(ts)) trav_inner(ts, w.ray, st);
+                            if (!trav_done(ts)) trav_leaf(ts, w.ray, st);
+                        }
+                    }
+                    walk_mesh_result(p.scene, w, ts, &cur);
+                    searches++;
+                    resume = true;
+                }
+                if (!park) {
+                    // the segment's trace is complete: work_group.rs:31-47
+                    traced++;
+                    V3 color = mk3(0, 0, 0);
+                    bool finished = true;
+                    if (cur.hit) {
+                        uint32_t s_local = path / p.geo.npp, q = path % p.geo.npp;
+                        uint32_t x, y;
+                        bool valid;
+                        path_slot_to_pixel(p.geo, q, &x, &y, &valid);
+                        Rng rng;
+                        rng.key = stream_key(p.seed, stream_id(p.sample_first + s_local, (uint64_t)x + (uint64_t)y * p.cam.width));
+                        rng.counter = rng_counter;
+                        V3 av, dir;
+                        bool is_color =
+                            material_get_color(p.scene.materials[cur.material_id], w.ray.direction, cur, rng, &av, &dir);
+                        rng_counter = rng.counter;
+                        if (is_color) {
+                            color = mult * av;
+                        } else if (depth + 1u < p.trace_depth) {
+                            nray.source = cur.point + dir * kEpsilon;
+                            nray.direction = dir;
+                            nray.min = kEpsilon;
+                            nray.max = kF32Max;
+                            nmult = mult * av;
+                            finished = false;
+                            emit = true;
+                        }
+                    }
+                    if (finished) {
+                        float* dst = contrib + (size_t)path * 3;
+                        dst[0] = color.x;
+                        dst[1] = color.y;
+                        dst[2] = color.z;
                     }
                 }
-                if (finished) {
-                    float* dst = contrib + (size_t)path * 3;
-                    dst[0] = color.x;
-                    dst[1] = color.y;
-                    dst[2] = color.z;
+            }
+            // parked rays: the search request, and (first segment) the generated ray itself
+            unsigned long long park_mask = __ballot(park);
+            if (park_mask != 0ull) {
+                if (park) {
+                    size_t j = base + job_pos + (uint32_t)__popcll(park_mask & lane_lt);
+                    const DNode& nd = p.scene.nodes[w.i];
+                    b.job_a[j] = make_float4(w.ray.source.x, w.ray.source.y, w.ray.source.z, w.ray.min);
+                    b.job_b[j] = make_float4(w.ray.direction.x, w.ray.direction.y, w.ray.direction.z, w.ray.max);
+                    b.job_c[j] = make_float4(__uint_as_float(v), __uint_as_float(nd.mesh_id), __uint_as_float(searches), 0.0f);
+                    if (FIRST && round == 0u) {
+                        b.ray_a[base + v] = make_float4(ray.source.x, ray.source.y, ray.source.z, ray.min);
+                        b.ray_b[base + v] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, __uint_as_float(path));
+                        b.ray_c[base + v] = make_float4(mult.x, mult.y, mult.z, __uint_as_float(rng_counter));
+                    }
                 }
+                job_pos += (uint32_t)__popcll(park_mask);
+            }
+            // surviving paths go to this region of the next segment's queue
+            unsigned long long emit_mask = __ballot(emit);
+            if (emit_mask != 0ull) {
+                if (emit) {
+                    size_t slot = base + out_pos + (uint32_t)__popcll(emit_mask & lane_lt);
+                    b.next_a[slot] = make_float4(nray.source.x, nray.source.y, nray.source.z, nray.min);
+                    b.next_b[slot] = make_float4(nray.direction.x, nray.direction.y, nray.direction.z, __uint_as_float(path));
+                    b.next_c[slot] = make_float4(nmult.x, nmult.y, nmult.z, __uint_as_float(rng_counter));
+                }
+                out_pos += (uint32_t)__popcll(emit_mask);
             }
         }
-        // ---- surviving paths go to this wave's region of the output queue
-        unsigned long long emit_mask = __ballot(emit);
-        if (emit_mask != 0ull) {
-            if (emit) {
-                size_t slot = region + out_pos + (uint32_t)__popcll(emit_mask & lane_lt);
-                oa[slot] = make_float4(nray.source.x, nray.source.y, nray.source.z, nray.min);
-                ob[slot] = make_float4(nray.direction.x, nray.direction.y, nray.direction.z, __uint_as_float(path));
-                oc[slot] = make_float4(nmult.x, nmult.y, nmult.z, __uint_as_float(rng_counter));
-            }
-            out_pos += (uint32_t)__popcll(emit_mask);
-        }
-
-        // ---- BVH searches
-        unsigned long long search_mask = __ballot(phase == 1u);
-        if (search_mask == 0ull) {
-            if (next >= nin && __ballot(phase != 0u) == 0ull) break;
-            continue;
-        }
-        const uint32_t n_search = (uint32_t)__popcll(search_mask);
-        for (;;) {
-            while (phase == 1u && trav_is_inner(ts)) trav_inner(ts, w.ray, st);
-            if (phase == 1u && !trav_done(ts)) trav_leaf(ts, w.ray, st);
-            unsigned long long unfinished = __ballot(phase == 1u && !trav_done(ts));
-            uint32_t n_unfinished = (uint32_t)__popcll(unfinished);
-            if (n_unfinished == 0u || n_unfinished + kRefill <= n_search) break;
-        }
-        if (phase == 1u && trav_done(ts)) {
-            walk_mesh_result(p.scene, w, ts, &cur);
-            phase = 2u;
+        if (lane == 0u) {
+            if (b.next_counts) b.next_counts[r] = out_pos;
+            if (b.job_counts) b.job_counts[r] = job_pos;
         }
     }
-    // ---- wave epilogue: queue length of the region, rays traced
     unsigned long long traced_total = 0;
     {
         uint32_t v = traced;
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
         traced_total = v;
     }
-    if (lane == 0u) {
-        if (counts_out) counts_out[wave] = out_pos;
-        if (traced_total) atomicAdd(ray_total, traced_total);
+    if (lane == 0u && traced_total) atomicAdd(ray_total, traced_total);
+}
+
+// -------------------------------------------------------------- search kernel
+// The BVH searches requested by walk_kernel.  This is where the time goes, so
+// the kernel carries nothing but the search: ~64 registers per lane, 8 waves per
+// SIMD to cover the latency of the dependent node fetches.  Lanes do not wait for
+// the slowest search of their wave: each lane is a small state machine and the
+// wave hands idle lanes new jobs whenever kRefill searches have finished (search
+// lengths differ by an order of magnitude between neighbouring rays).
+__global__ void __launch_bounds__(kBlock, PT_SEARCH_OCCUPANCY)
+search_kernel(const DMesh* __restrict__ meshes, const float4* __restrict__ job_a, const float4* __restrict__ job_b,
+              const float4* __restrict__ job_c, const uint32_t* __restrict__ job_counts, SegmentBuffers b, uint32_t cap,
+              uint32_t regions, uint32_t* spill, uint32_t spill_threads) {
+    __shared__ int32_t lds_stack[kLdsStack * kBlock];
+    const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+    const uint32_t waves = (gridDim.x * kBlock) >> 6;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    TravStack st = make_stack(lds_stack, spill, spill_threads);
+
+    uint32_t region = wave;                                   // region being drained (wave-uniform)
+    uint32_t n_jobs = region < regions ? job_counts[region] : 0u;
+    uint32_t next = 0u;
+    TravState ts;
+    ts.cur = kBvhSentinel;
+    Ray ray;
+    float4* res_out = nullptr;
+    bool busy = false;
+
+    for (;;) {
+        // ---- hand jobs to idle lanes
+        unsigned long long idle_mask = __ballot(!busy);
+        while (idle_mask != 0ull && region < regions) {
+            uint32_t avail = n_jobs - next;
+            if (avail == 0u) {
+                region += waves;
+                next = 0u;
+                n_jobs = region < regions ? job_counts[region] : 0u;
+                continue;
+            }
+            uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+            uint32_t rank = (uint32_t)__popcll(idle_mask & lane_lt);
+            if (!busy && rank < avail) {
+                size_t j = (size_t)region * cap + next + rank;
+                float4 ja = job_a[j], jb = job_b[j], jc = job_c[j];
+                ray.source = mk3(ja.x, ja.y, ja.z);
+                ray.min = ja.w;
+                ray.direction = mk3(jb.x, jb.y, jb.z);
+                ray.max = jb.w;
+                uint32_t v = __float_as_uint(jc.x), mesh_id = __float_as_uint(jc.y), k = __float_as_uint(jc.z);
+                res_out = b.res[k] + ((size_t)region * cap + v);
+                const DMesh& mesh = meshes[mesh_id];
+                // the walk kernel has already checked the ray against the mesh bounds
+                ts.inv = mk3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
+                ts.ray_limit = (ray.max == ray.max) ? ray.max : f32_inf();
+                ts.nodes = mesh.nodes;
+                ts.tris = mesh.tris;
+                ts.cur = mesh.root_ref;
+                ts.tbest = f32_inf();
+                ts.best_slot = 0u;
+                ts.best_orig = 0xFFFFFFFFu;
+                ts.found = 0u;
+                st.sp = 0;
+                busy = true;
+            }
+            next += n_idle < avail ? n_idle : avail;
+            idle_mask = __ballot(!busy);
+        }
+        unsigned long long busy_mask = __ballot(busy);
+        if (busy_mask == 0ull) break; // no job left for this wave
+        const uint32_t n_busy = (uint32_t)__popcll(busy_mask);
+        const bool more = region < regions;
+        // ---- search until enough lanes are done to make a refill worthwhile
+        for (;;) {
+            while (busy && trav_is_inner(ts)) trav_inner(ts, ray, st);
+            if (busy && !trav_done(ts)) trav_leaf(ts, ray, st);
+            uint32_t n_unfinished = (uint32_t)__popcll(__ballot(busy && !trav_done(ts)));
+            if (n_unfinished == 0u || (more && n_unfinished + kRefill <= n_busy)) break;
+        }
+        if (busy && trav_done(ts)) {
+            *res_out = make_float4(ts.tbest, __uint_as_float(ts.found), __uint_as_float(ts.best_slot),
+                                   __uint_as_float(ts.best_orig));
+            busy = false;
+        }
     }
 }
 
@@ -386,7 +491,7 @@ static inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kBlock - 
 
 hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeometry& geo, uint64_t seed,
                         uint64_t sample_first, uint32_t sample_count, uint32_t trace_depth, bool brute,
-                        Workspace& ws, float* d_accum, hipStream_t stream,
+                        uint32_t mesh_nodes, Workspace& ws, float* d_accum, hipStream_t stream,
                         std::vector<hipEvent_t>* segment_events) {
     RenderParams p;
     p.scene = scene;
@@ -400,9 +505,14 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
     uint64_t total = (uint64_t)sample_count * geo.npp;
     if (total == 0 || trace_depth == 0) return hipSuccess;
     if (!ws.spill || ws.persistent_blocks == 0 || total > 0xFFFFFFFFull) return hipErrorInvalidValue;
-    const uint32_t waves = ws.persistent_blocks * (kBlock / 64);
-    const uint32_t cap = queue_region_capacity(total, waves);
-    if ((uint64_t)cap * waves > ws.capacity_paths || total > ws.contrib_paths) return hipErrorInvalidValue;
+    const uint32_t regions = ws.persistent_blocks * (kBlock / 64);
+    const uint32_t cap = queue_region_capacity(total, regions);
+    if ((uint64_t)cap * regions > ws.capacity_paths || total > ws.contrib_paths) return hipErrorInvalidValue;
+    // rounds of (walk, search) per segment: one per mesh a ray may have to search, at most kMaxDeferred;
+    // the linear-scan mode never defers
+    const uint32_t rounds = brute ? 0u : std::min<uint32_t>(mesh_nodes, (uint32_t)kMaxDeferred);
+    const uint32_t spill_threads = ws.persistent_blocks * kBlock;
+    unsigned long long* rt = reinterpret_cast<unsigned long long*>(ws.ray_total);
     hipError_t e;
     for (uint32_t d = 0; d < trace_depth; d++) {
         int in = d & 1, out = in ^ 1;
@@ -414,17 +524,36 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
             segment_events->push_back(e1);
             if ((e = hipEventRecord(e0, stream)) != hipSuccess) return e;
         }
-        uint32_t* counts_out = (d + 1 < trace_depth) ? ws.wave_counts[out] : nullptr;
-        unsigned long long* rt = reinterpret_cast<unsigned long long*>(ws.ray_total);
-        if (d == 0)
-            segment_kernel<true><<<ws.persistent_blocks, kBlock, 0, stream>>>(
-                p, d, cap, nullptr, nullptr, nullptr, ws.queue[out][0], ws.queue[out][1], ws.queue[out][2], nullptr,
-                counts_out, ws.contrib, rt, ws.spill, ws.persistent_blocks * kBlock);
-        else
-            segment_kernel<false><<<ws.persistent_blocks, kBlock, 0, stream>>>(
-                p, d, cap, ws.queue[in][0], ws.queue[in][1], ws.queue[in][2], ws.queue[out][0], ws.queue[out][1],
-                ws.queue[out][2], ws.wave_counts[in], counts_out, ws.contrib, rt, ws.spill,
-                ws.persistent_blocks * kBlock);
+        for (uint32_t r = 0; r <= rounds; r++) {
+            int jcur = r & 1, jprev = jcur ^ 1;
+            SegmentBuffers b;
+            b.ray_a = ws.queue[in][0];
+            b.ray_b = ws.queue[in][1];
+            b.ray_c = ws.queue[in][2];
+            b.ray_counts = ws.wave_counts[in];
+            b.next_a = ws.queue[out][0];
+            b.next_b = ws.queue[out][1];
+            b.next_c = ws.queue[out][2];
+            b.next_counts = ws.wave_counts[out];
+            b.job_a = ws.jobs[jcur][0];
+            b.job_b = ws.jobs[jcur][1];
+            b.job_c = ws.jobs[jcur][2];
+            b.job_counts = ws.job_counts[jcur];
+            b.prev_job_c = ws.jobs[jprev][2];
+            b.prev_job_counts = ws.job_counts[jprev];
+            for (int k = 0; k < kMaxDeferred; k++) b.res[k] = ws.results[k];
+            uint32_t defer = r < rounds ? 1u : 0u;
+            if (d == 0)
+                walk_kernel<true><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, r, defer, b, cap, regions, ws.contrib,
+                                                                               rt, ws.spill, spill_threads);
+            else
+                walk_kernel<false><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, r, defer, b, cap, regions,
+                                                                                ws.contrib, rt, ws.spill, spill_threads);
+            if (defer)
+                search_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(scene.meshes, b.job_a, b.job_b, b.job_c,
+                                                                          b.job_counts, b, cap, regions, ws.spill,
+                                                                          spill_threads);
+        }
         if (segment_events && (e = hipEventRecord(e1, stream)) != hipSuccess) return e;
     }
     accumulate_kernel<<<blocks_for(geo.npp), kBlock, 0, stream>>>(geo, cam.width, sample_count, ws.contrib, d_accum);
