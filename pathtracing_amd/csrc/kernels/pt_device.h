@@ -475,87 +475,147 @@ __device__ __forceinline__ void walk_begin(WalkState& w, const Ray& ray) {
     w.depth = 0;
 }
 
-__device__ __forceinline__ void walk_deliver(const DScene& sc, WalkState& w, const Hit& cur) {
-    if (w.open != 0xFFFFFFFFu && sc.nodes[w.open].type == 0u && cur.hit && cur.t < w.best.t) w.best = cur;
+// Node records are read through the constant address space with a wave-uniform
+// index, so they arrive by scalar loads into SGPRs (one fetch per wave, no vector
+// registers): every lane of a wave is always at the same node, because which node
+// comes next never depends on the ray.
+typedef const __attribute__((address_space(4))) DNode* ConstNodePtr;
+__device__ __forceinline__ ConstNodePtr const_nodes(const DScene& sc) {
+    return (ConstNodePtr)(unsigned long long)(sc.nodes);
+}
+__device__ __forceinline__ V3 cv3(const __attribute__((address_space(4))) V3& v) { return mk3(v.x, v.y, v.z); }
+
+// &Mat4 * Vec4::from_vec3(p) (lib.rs:519-526, :651-659) with the matrix in scalar registers
+__device__ __forceinline__ V3 mul_point_c(const __attribute__((address_space(4))) M4& a, V3 p) {
+    float w = p.x * a.m[3][0] + p.y * a.m[3][1] + p.z * a.m[3][2] + 1.0f * a.m[3][3];
+    V3 r = mk3(p.x * a.m[0][0] + p.y * a.m[0][1] + p.z * a.m[0][2] + 1.0f * a.m[0][3],
+               p.x * a.m[1][0] + p.y * a.m[1][1] + p.z * a.m[1][2] + 1.0f * a.m[1][3],
+               p.x * a.m[2][0] + p.y * a.m[2][1] + p.z * a.m[2][2] + 1.0f * a.m[2][3]);
+    return r / w;
+}
+__device__ __forceinline__ V3 mul_c(const __attribute__((address_space(4))) M3& a, V3 rhs) {
+    return mk3(dot(rhs, cv3(a.row0)), dot(rhs, cv3(a.row1)), dot(rhs, cv3(a.row2)));
 }
 
 __device__ __forceinline__ int walk(const DScene& sc, WalkState& w, Hit& cur, bool resume, bool brute, TravStack& st,
                                     TravState& ts) {
     const uint32_t n = sc.node_count;
+    ConstNodePtr nodes = const_nodes(sc);
+    // wave-uniform cursor (see above)
+    uint32_t i = __builtin_amdgcn_readfirstlane(w.i);
+    uint32_t open = __builtin_amdgcn_readfirstlane(w.open);
+    int depth = (int)__builtin_amdgcn_readfirstlane((uint32_t)w.depth);
+    bool open_is_collection = open != 0xFFFFFFFFu && nodes[open].type == 0u;
     if (resume) {
-        w.i++;
-        walk_deliver(sc, w, cur);
+        i++;
+        if (open_is_collection && cur.hit && cur.t < w.best.t) w.best = cur;
     }
+    int status = kWalkDone;
     for (;;) {
-        while (w.open != 0xFFFFFFFFu && w.i == sc.nodes[w.open].end) {
-            const DNode& on = sc.nodes[w.open];
-            w.depth--;
-            if (on.type == 0u) {
+        while (open != 0xFFFFFFFFu && i == nodes[open].end) {
+            depth--;
+            if (nodes[open].type == 0u) {
                 cur = w.best;
-                if (w.depth > 0) w.best = spill_load_hit(st, w.depth);
+                if (depth > 0) w.best = spill_load_hit(st, depth);
             } else {
-                w.ray = spill_load_ray(st, w.depth);
+                w.ray = spill_load_ray(st, depth);
                 if (cur.hit) {
-                    V3 point = mul_point(on.matrix, cur.point);
+                    V3 point = mul_point_c(nodes[open].matrix, cur.point);
                     cur.t = length(point - w.ray.source);
                     cur.point = point;
-                    cur.normal = mul(on.normal_matrix, cur.normal);
+                    cur.normal = mul_c(nodes[open].normal_matrix, cur.normal);
                 }
             }
-            w.open = on.parent;
-            walk_deliver(sc, w, cur);
+            open = nodes[open].parent;
+            open_is_collection = open != 0xFFFFFFFFu && nodes[open].type == 0u;
+            if (open_is_collection && cur.hit && cur.t < w.best.t) w.best = cur;
         }
-        if (w.i >= n) return kWalkDone;
-        const DNode& nd = sc.nodes[w.i];
-        uint32_t type = nd.type;
+        if (i >= n) break;
+        uint32_t type = nodes[i].type;
         if (type == 0u) { // collection
-            if (w.depth > 0) spill_store_hit(st, w.depth, w.best);
-            w.depth++;
-            w.open = w.i;
+            if (depth > 0) spill_store_hit(st, depth, w.best);
+            depth++;
+            open = i;
+            open_is_collection = true;
             w.best.hit = 0u;
             w.best.hit_inside = 0u;
             w.best.t = f32_inf();
-            w.i++;
+            i++;
             continue;
         }
-        if (type == 1u) { // transform
-            spill_store_ray(st, w.depth, w.ray);
-            w.depth++;
-            w.open = w.i;
-            w.ray = apply_transform(w.ray, nd.matrix_inverse, nd.inverse_normal_matrix);
-            w.i++;
+        if (type == 1u) { // transform: ray.rs:21-37 with normal_matrix() of the inverse precomputed
+            spill_store_ray(st, depth, w.ray);
+            depth++;
+            open = i;
+            open_is_collection = false;
+            const Ray r = w.ray;
+            V3 min_point = r.min * r.direction + r.source;
+            V3 max_point = r.max * r.direction + r.source;
+            V3 s = mul_point_c(nodes[i].matrix_inverse, r.source);
+            V3 mn = mul_point_c(nodes[i].matrix_inverse, min_point);
+            V3 mx = mul_point_c(nodes[i].matrix_inverse, max_point);
+            w.ray.source = s;
+            w.ray.direction = mul_c(nodes[i].inverse_normal_matrix, r.direction);
+            w.ray.min = length(mn - s);
+            w.ray.max = length(mx - s);
+            i++;
             continue;
         }
         if (type == 5u) { // kd_tree
-            w.i++;
+            i++;
             continue;
         }
         if (type == 2u) {
+            DNode nd;
+            nd.material_id = nodes[i].material_id;
+            nd.mesh_id = nodes[i].mesh_id;
             const DMesh& mesh = sc.meshes[nd.mesh_id];
             if (brute) {
                 float t;
                 uint32_t slot;
                 bool found = mesh_closest_linear(mesh, w.ray, &t, &slot);
-                mesh_result(mesh, nd, w.i, w.ray, found, t, mesh.tris_orig + slot, slot, &cur);
+                mesh_result(mesh, nd, i, w.ray, found, t, mesh.tris_orig + slot, slot, &cur);
             } else {
-                if (trav_begin(mesh, w.ray, st, ts)) return kWalkMesh;
-                mesh_result(mesh, nd, w.i, w.ray, false, 0.0f, nullptr, 0u, &cur);
+                if (trav_begin(mesh, w.ray, st, ts)) {
+                    status = kWalkMesh;
+                    break;
+                }
+                mesh_result(mesh, nd, i, w.ray, false, 0.0f, nullptr, 0u, &cur);
             }
         } else if (type == 3u) {
-            sphere_trace(nd, w.i, w.ray, &cur);
+            DNode nd;
+            nd.center = cv3(nodes[i].center);
+            nd.radius = nodes[i].radius;
+            nd.radius_sqr = nodes[i].radius_sqr;
+            nd.material_id = nodes[i].material_id;
+            sphere_trace(nd, i, w.ray, &cur);
         } else {
-            plane_trace(nd, w.i, w.ray, &cur);
+            DNode nd;
+            nd.point = cv3(nodes[i].point);
+            nd.normal = cv3(nodes[i].normal);
+            nd.tangent = cv3(nodes[i].tangent);
+            nd.bitangent = cv3(nodes[i].bitangent);
+            nd.material_id = nodes[i].material_id;
+            plane_trace(nd, i, w.ray, &cur);
         }
-        w.i++;
-        walk_deliver(sc, w, cur);
+        i++;
+        if (open_is_collection && cur.hit && cur.t < w.best.t) w.best = cur;
     }
+    w.i = i;
+    w.open = open;
+    w.depth = depth;
+    return status;
 }
 
 // The result of the mesh node the walk stopped at, from a finished search.
 __device__ __forceinline__ void walk_mesh_result(const DScene& sc, const WalkState& w, const TravState& ts, Hit* cur) {
-    const DNode& nd = sc.nodes[w.i];
+    ConstNodePtr nodes = const_nodes(sc);
+    uint32_t i = __builtin_amdgcn_readfirstlane(w.i);
+    DNode nd;
+    nd.material_id = nodes[i].material_id;
+    nd.mesh_id = nodes[i].mesh_id;
     const DMesh& mesh = sc.meshes[nd.mesh_id];
-    mesh_result(mesh, nd, w.i, w.ray, ts.found != 0u, ts.tbest, ts.tris + ts.best_slot, ts.best_orig, cur);
+    mesh_result(mesh, nd, i, w.ray, ts.found != 0u, ts.tbest, mesh.tris + ts.best_slot, ts.best_orig, cur);
 }
 
 // scene.hierarchy.trace_ray for one ray, every search run to its end in place.

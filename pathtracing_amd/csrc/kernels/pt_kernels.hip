@@ -91,8 +91,11 @@ struct SegmentBuffers {
 // second walk repeats the first bit for bit; re-walking a handful of cheap nodes
 // costs less than saving and restoring the walk's state).  `defer` = false (last
 // round) or more than kMaxDeferred searches on one ray: the search runs in place.
+#ifndef PT_WALK_OCCUPANCY
+#define PT_WALK_OCCUPANCY 3
+#endif
 template <bool FIRST>
-__global__ void __launch_bounds__(kBlock, 4)
+__global__ void __launch_bounds__(kBlock, PT_WALK_OCCUPANCY)
 walk_kernel(RenderParams p, uint32_t depth, uint32_t round, uint32_t defer, SegmentBuffers b, uint32_t cap,
             uint32_t regions, float* contrib, unsigned long long* ray_total, uint32_t* spill, uint32_t spill_threads) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
@@ -186,6 +189,7 @@ walk_kernel(RenderParams p, uint32_t depth, uint32_t round, uint32_t defer, Segm
                         ts.found = __float_as_uint(res.y);
                         ts.best_slot = __float_as_uint(res.z);
                         ts.best_orig = __float_as_uint(res.w);
+                        ts.tris = nullptr; // walk_mesh_result takes the triangle array from the mesh
                     } else if (defer != 0u && searches < (uint32_t)kMaxDeferred) {
                         park = true;
                         break;
@@ -241,10 +245,10 @@ walk_kernel(RenderParams p, uint32_t depth, uint32_t round, uint32_t defer, Segm
             if (park_mask != 0ull) {
                 if (park) {
                     size_t j = base + job_pos + (uint32_t)__popcll(park_mask & lane_lt);
-                    const DNode& nd = p.scene.nodes[w.i];
+                    const uint32_t mesh_id = const_nodes(p.scene)[__builtin_amdgcn_readfirstlane(w.i)].mesh_id;
                     b.job_a[j] = make_float4(w.ray.source.x, w.ray.source.y, w.ray.source.z, w.ray.min);
                     b.job_b[j] = make_float4(w.ray.direction.x, w.ray.direction.y, w.ray.direction.z, w.ray.max);
-                    b.job_c[j] = make_float4(__uint_as_float(v), __uint_as_float(nd.mesh_id), __uint_as_float(searches), 0.0f);
+                    b.job_c[j] = make_float4(__uint_as_float(v), __uint_as_float(mesh_id), __uint_as_float(searches), 0.0f);
                     if (FIRST && round == 0u) {
                         b.ray_a[base + v] = make_float4(ray.source.x, ray.source.y, ray.source.z, ray.min);
                         b.ray_b[base + v] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, __uint_as_float(path));
