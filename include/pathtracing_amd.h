@@ -190,8 +190,8 @@ typedef struct PtRenderTask {
 } PtRenderTask;
 
 #define PT_FLAG_BRUTE_FORCE 1u /* scan every triangle like mesh/mod.rs:57-62 (no BVH) */
-#define PT_FLAG_PROFILE 2u     /* time every path-segment kernel launch with events on the
-                                  render stream (fills PtRenderStats.segment_*); slower */
+#define PT_FLAG_PROFILE 2u     /* time every launch of the BVH search kernel with events on the
+                                  render stream (fills PtRenderStats.search_kernel_*); slower  */
 
 /* Knobs the reference does not have.  A NULL pointer means all zero. */
 typedef struct PtRenderOpts {
@@ -208,9 +208,10 @@ typedef struct PtRenderStats {
     uint64_t paths;
     double render_ms;     /* device time of the render itself                          */
     uint64_t bvh_bytes;   /* device bytes of nodes + triangles of all meshes           */
-    double segment_kernel_ms;         /* PT_FLAG_PROFILE: summed duration of the path-segment
-                                         (trace + shade) kernel launches                      */
-    uint64_t segment_kernel_launches; /* PT_FLAG_PROFILE: how many launches that sum covers  */
+    uint64_t searches;    /* BVH searches run (rays that reached a mesh's bounds)        */
+    double search_kernel_ms;         /* PT_FLAG_PROFILE: summed duration of the BVH search
+                                        kernel launches                                        */
+    uint64_t search_kernel_launches; /* PT_FLAG_PROFILE: how many launches that sum covers    */
 } PtRenderStats;
 
 /* Renderer::render (renderer/mod.rs:12) -> Rgb32FImage: fills out_rgb

@@ -159,8 +159,9 @@ class PtRenderStats(C.Structure):
         ("paths", C.c_uint64),
         ("render_ms", C.c_double),
         ("bvh_bytes", C.c_uint64),
-        ("segment_kernel_ms", C.c_double),
-        ("segment_kernel_launches", C.c_uint64),
+        ("searches", C.c_uint64),
+        ("search_kernel_ms", C.c_double),
+        ("search_kernel_launches", C.c_uint64),
     ]
 
 

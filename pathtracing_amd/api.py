@@ -103,7 +103,7 @@ class RenderOpts:
     brute_force: bool = False
     tile: Optional[tuple] = None  # (x0, y0, w, h) in camera space
     paths_per_batch: int = 0
-    profile: bool = False  # time each path-segment kernel launch (RenderStats.segment_kernel_ms)
+    profile: bool = False  # time each BVH search kernel launch (RenderStats.search_kernel_ms)
 
     def to_native(self) -> N.PtRenderOpts:
         o = N.PtRenderOpts()

@@ -68,7 +68,7 @@ struct PtScene {
     ptk::Workspace ws;
     uint64_t bvh_bytes = 0;
     uint32_t node_count = 0;
-    uint32_t mesh_nodes = 0; // mesh nodes in the scene graph = BVH searches one ray can need
+    std::vector<ptk::MeshTarget> targets; // the scene graph's mesh nodes = BVH searches one ray needs per segment
     std::vector<uint32_t> mesh_tri_count;
 
     void* dev_alloc(size_t bytes) {
@@ -89,12 +89,11 @@ struct PtScene {
                     (void)hipFree(ws.queue[q][k]);
                     ws.queue[q][k] = nullptr;
                 }
-        for (int q = 0; q < 2; q++)
-            for (int k = 0; k < 3; k++)
-                if (ws.jobs[q][k]) {
-                    (void)hipFree(ws.jobs[q][k]);
-                    ws.jobs[q][k] = nullptr;
-                }
+        for (int k = 0; k < 3; k++)
+            if (ws.jobs[k]) {
+                (void)hipFree(ws.jobs[k]);
+                ws.jobs[k] = nullptr;
+            }
         for (int k = 0; k < ptk::kMaxDeferred; k++)
             if (ws.results[k]) {
                 (void)hipFree(ws.results[k]);
@@ -116,12 +115,10 @@ struct PtScene {
         size_t bytes = (size_t)ws.persistent_blocks * ptk::kTraceBlock * ptk::spill_dwords_per_thread() * sizeof(uint32_t);
         hip_check(hipMalloc(reinterpret_cast<void**>(&ws.spill), bytes), "hipMalloc spill");
         size_t waves = (size_t)ws.persistent_blocks * (ptk::kTraceBlock / 64);
-        for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < 2; q++)
             hip_check(hipMalloc(reinterpret_cast<void**>(&ws.wave_counts[q]), waves * sizeof(uint32_t)), "hipMalloc counts");
-            hip_check(hipMalloc(reinterpret_cast<void**>(&ws.job_counts[q]), waves * sizeof(uint32_t)), "hipMalloc counts");
-            hip_check(hipMemset(ws.job_counts[q], 0, waves * sizeof(uint32_t)), "hipMemset");
-        }
-        hip_check(hipMalloc(reinterpret_cast<void**>(&ws.ray_total), sizeof(uint64_t)), "hipMalloc ray_total");
+        hip_check(hipMalloc(reinterpret_cast<void**>(&ws.job_counts), waves * sizeof(uint32_t)), "hipMalloc counts");
+        hip_check(hipMalloc(reinterpret_cast<void**>(&ws.ray_total), 2 * sizeof(uint64_t)), "hipMalloc ray_total");
     }
     void ensure_workspace(uint64_t paths) {
         ensure_trace_state();
@@ -132,10 +129,10 @@ struct PtScene {
         for (int q = 0; q < 2; q++)
             for (int k = 0; k < 3; k++)
                 hip_check(hipMalloc(reinterpret_cast<void**>(&ws.queue[q][k]), records * sizeof(float4)), "hipMalloc queue");
-        for (int q = 0; q < 2; q++)
+        uint32_t result_arrays = std::min<uint32_t>((uint32_t)targets.size(), (uint32_t)ptk::kMaxDeferred);
+        if (result_arrays)
             for (int k = 0; k < 3; k++)
-                hip_check(hipMalloc(reinterpret_cast<void**>(&ws.jobs[q][k]), records * sizeof(float4)), "hipMalloc jobs");
-        uint32_t result_arrays = std::min<uint32_t>(std::max<uint32_t>(mesh_nodes, 1u), (uint32_t)ptk::kMaxDeferred);
+                hip_check(hipMalloc(reinterpret_cast<void**>(&ws.jobs[k]), records * sizeof(float4)), "hipMalloc jobs");
         for (uint32_t k = 0; k < result_arrays; k++)
             hip_check(hipMalloc(reinterpret_cast<void**>(&ws.results[k]), records * sizeof(float4)), "hipMalloc results");
         hip_check(hipMalloc(reinterpret_cast<void**>(&ws.contrib), paths * 3 * sizeof(float)), "hipMalloc contrib");
@@ -144,10 +141,9 @@ struct PtScene {
     }
     ~PtScene() {
         free_workspace();
-        for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < 2; q++)
             if (ws.wave_counts[q]) (void)hipFree(ws.wave_counts[q]);
-            if (ws.job_counts[q]) (void)hipFree(ws.job_counts[q]);
-        }
+        if (ws.job_counts) (void)hipFree(ws.job_counts);
         if (ws.ray_total) (void)hipFree(ws.ray_total);
         if (ws.spill) (void)hipFree(ws.spill);
         for (void* p : allocs) (void)hipFree(p);
@@ -370,7 +366,7 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
     if (stats) {
         hip_check(hipEventCreate(&ev0), "hipEventCreate");
         hip_check(hipEventCreate(&ev1), "hipEventCreate");
-        hip_check(hipMemsetAsync(scene->ws.ray_total, 0, sizeof(uint64_t), stream), "hipMemsetAsync");
+        hip_check(hipMemsetAsync(scene->ws.ray_total, 0, 2 * sizeof(uint64_t), stream), "hipMemsetAsync");
         hip_check(hipEventRecord(ev0, stream), "hipEventRecord");
     }
     bool brute = (o.flags & PT_FLAG_BRUTE_FORCE) != 0;
@@ -395,7 +391,7 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
         for (uint64_t s = 0; s < task->iterations; s += samples_per_batch) {
             uint32_t cnt = (uint32_t)std::min<uint64_t>(samples_per_batch, task->iterations - s);
             hip_check(ptk::render_batch(scene->d, cam, g, o.seed, o.sample_offset + s, cnt, (uint32_t)task->trace_depth,
-                                        brute, scene->mesh_nodes, scene->ws, d_accum, stream,
+                                        brute, scene->targets, scene->ws, d_accum, stream,
                                         profile ? &seg_events : nullptr),
                       "render_batch");
             paths += (uint64_t)cnt * g.w * g.h;
@@ -406,21 +402,23 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
         hip_check(hipEventSynchronize(ev1), "hipEventSynchronize");
         float ms = 0.0f;
         hip_check(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime");
-        uint64_t rays = 0;
-        hip_check(hipMemcpy(&rays, scene->ws.ray_total, sizeof(rays), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+        uint64_t totals[2] = {0, 0};
+        hip_check(hipMemcpy(totals, scene->ws.ray_total, sizeof(totals), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+        uint64_t rays = totals[0];
         (void)hipEventDestroy(ev0);
         (void)hipEventDestroy(ev1);
         stats->rays = task->trace_depth ? rays : 0;
         stats->paths = paths;
         stats->render_ms = ms;
         stats->bvh_bytes = scene->bvh_bytes;
-        stats->segment_kernel_ms = 0.0;
-        stats->segment_kernel_launches = 0;
+        stats->searches = totals[1];
+        stats->search_kernel_ms = 0.0;
+        stats->search_kernel_launches = 0;
         for (size_t i = 0; i + 1 < seg_events.size(); i += 2) {
             float seg = 0.0f;
             hip_check(hipEventElapsedTime(&seg, seg_events[i], seg_events[i + 1]), "hipEventElapsedTime");
-            stats->segment_kernel_ms += seg;
-            stats->segment_kernel_launches++;
+            stats->search_kernel_ms += seg;
+            stats->search_kernel_launches++;
         }
     }
 }
@@ -458,8 +456,20 @@ PtStatus pt_scene_create(const PtSceneDesc* desc, int device, PtScene** out_scen
         std::vector<ptk::DNode> nodes;
         layout_nodes(*desc, nodes);
         s->node_count = desc->node_count;
-        for (uint32_t i = 0; i < desc->node_count; i++)
-            if (desc->nodes[i].type == PT_NODE_MESH) s->mesh_nodes++;
+        for (uint32_t i = 0; i < desc->node_count; i++) {
+            if (nodes[i].type != PT_NODE_MESH) continue;
+            ptk::MeshTarget t{};
+            t.node_index = i;
+            t.mesh_id = nodes[i].mesh_id;
+            uint32_t above[ptk::kMaxGraphDepth];
+            uint32_t n_above = 0;
+            for (uint32_t a = nodes[i].parent; a != 0xFFFFFFFFu; a = nodes[a].parent)
+                if (nodes[a].type == PT_NODE_TRANSFORM) above[n_above++] = a;
+            t.chain_len = n_above;
+            for (uint32_t c = 0; c < n_above; c++) t.chain[c] = above[n_above - 1 - c];
+            nodes[i].mesh_ordinal = (uint32_t)s->targets.size();
+            s->targets.push_back(t);
+        }
 
         // a kd_tree node directly above a mesh node offers its .tree blob to that mesh
         std::vector<const PtTreeBlob*> mesh_blob(desc->mesh_count, nullptr);

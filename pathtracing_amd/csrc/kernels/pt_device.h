@@ -329,8 +329,8 @@ struct TravState {
     uint32_t best_slot, best_orig, found;
 };
 
-// Starts a search.  False: the ray cannot hit the mesh at all.
-__device__ __forceinline__ bool trav_begin(const DMesh& mesh, const Ray& ray, TravStack& st, TravState& ts) {
+// False: the ray cannot hit any triangle of the mesh.
+__device__ __forceinline__ bool trav_reaches(const DMesh& mesh, const Ray& ray) {
     // A ray with a NaN or infinite origin or direction component cannot hit any
     // triangle: in triangle_hit the non-finite value reaches u = (tvec.pvec)/det
     // as an infinity or a NaN and fails 0 <= u <= 1 (the linear scan would test
@@ -338,19 +338,28 @@ __device__ __forceinline__ bool trav_begin(const DMesh& mesh, const Ray& ray, Tr
     // cosine-weighted sampler takes sqrt(cos(f32 pi/2)) = sqrt(-4.4e-8) when its
     // random number is exactly 0.
     if (!all_finite(ray.source) || !all_finite(ray.direction)) return false;
-    ts.inv = mk3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
-    ts.ray_limit = (ray.max == ray.max) ? ray.max : f32_inf();
+    V3 inv = mk3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
+    float limit = (ray.max == ray.max) ? ray.max : f32_inf();
     float entry;
-    if (!box_test(mesh.bmin, mesh.bmax, ray.source, ts.inv, ts.ray_limit, &entry)) return false;
-    if (mesh.root_ref == kBvhSentinel) return false;
+    if (!box_test(mesh.bmin, mesh.bmax, ray.source, inv, limit, &entry)) return false;
+    return mesh.root_ref != kBvhSentinel;
+}
+
+// Starts a search.  False: the ray cannot hit the mesh at all; `ts` then
+// describes a finished search without a hit.
+__device__ __forceinline__ bool trav_begin(const DMesh& mesh, const Ray& ray, TravStack& st, TravState& ts) {
     ts.nodes = mesh.nodes;
     ts.tris = mesh.tris;
-    ts.cur = mesh.root_ref;
+    ts.cur = kBvhSentinel; // until the checks below pass: a finished search without a hit
     ts.tbest = f32_inf();
     ts.best_slot = 0u;
     ts.best_orig = 0xFFFFFFFFu;
     ts.found = 0u;
     st.sp = 0;
+    if (!trav_reaches(mesh, ray)) return false;
+    ts.inv = mk3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
+    ts.ray_limit = (ray.max == ray.max) ? ray.max : f32_inf();
+    ts.cur = mesh.root_ref;
     return true;
 }
 
@@ -444,10 +453,12 @@ __device__ __forceinline__ void mesh_result(const DMesh& mesh, const DNode& n, u
 //   transform (transform.rs:45-66): child sees apply_transform(ray, M^-1); a hit
 //     comes back as point = M*point', t = |point - ray.source|, normal = N*normal';
 //   kd_tree: its child.
-// The walk is resumable: at a mesh node whose BVH has to be searched it returns
-// kWalkMesh with the search set up in `ts`; the caller runs the search (possibly
-// interleaved with other lanes' work), stores the node's result in `cur` and
-// calls walk() again with resume = true.  The saved state of the open internal
+// The walk is resumable: at a mesh node (unless `brute`) it returns kWalkMesh with
+// w.ray = the ray in the mesh's space; the caller supplies the closest triangle
+// (from a search it runs, or one that ran earlier), stores the node's result in
+// `cur` with walk_mesh_result and calls walk() again with resume = true.  Which
+// node comes next never depends on the ray, so all lanes of a wave stop at the
+// same nodes.  The saved state of the open internal
 // nodes (outer ray of a transform, running best of an enclosing collection)
 // lives in the lane's spill column, indexed by nesting depth.
 struct WalkState {
@@ -497,8 +508,23 @@ __device__ __forceinline__ V3 mul_c(const __attribute__((address_space(4))) M3& 
     return mk3(dot(rhs, cv3(a.row0)), dot(rhs, cv3(a.row1)), dot(rhs, cv3(a.row2)));
 }
 
-__device__ __forceinline__ int walk(const DScene& sc, WalkState& w, Hit& cur, bool resume, bool brute, TravStack& st,
-                                    TravState& ts) {
+// Ray::apply_transform (ray.rs:21-37) for a transform node read through scalar
+// loads; the same arithmetic as apply_transform above.
+__device__ __forceinline__ Ray transform_ray_c(const __attribute__((address_space(4))) DNode& node, const Ray& r) {
+    V3 min_point = r.min * r.direction + r.source;
+    V3 max_point = r.max * r.direction + r.source;
+    V3 s = mul_point_c(node.matrix_inverse, r.source);
+    V3 mn = mul_point_c(node.matrix_inverse, min_point);
+    V3 mx = mul_point_c(node.matrix_inverse, max_point);
+    Ray o;
+    o.source = s;
+    o.direction = mul_c(node.inverse_normal_matrix, r.direction);
+    o.min = length(mn - s);
+    o.max = length(mx - s);
+    return o;
+}
+
+__device__ __forceinline__ int walk(const DScene& sc, WalkState& w, Hit& cur, bool resume, bool brute, TravStack& st) {
     const uint32_t n = sc.node_count;
     ConstNodePtr nodes = const_nodes(sc);
     // wave-uniform cursor (see above)
@@ -548,16 +574,7 @@ __device__ __forceinline__ int walk(const DScene& sc, WalkState& w, Hit& cur, bo
             depth++;
             open = i;
             open_is_collection = false;
-            const Ray r = w.ray;
-            V3 min_point = r.min * r.direction + r.source;
-            V3 max_point = r.max * r.direction + r.source;
-            V3 s = mul_point_c(nodes[i].matrix_inverse, r.source);
-            V3 mn = mul_point_c(nodes[i].matrix_inverse, min_point);
-            V3 mx = mul_point_c(nodes[i].matrix_inverse, max_point);
-            w.ray.source = s;
-            w.ray.direction = mul_c(nodes[i].inverse_normal_matrix, r.direction);
-            w.ray.min = length(mn - s);
-            w.ray.max = length(mx - s);
+            w.ray = transform_ray_c(nodes[i], w.ray);
             i++;
             continue;
         }
@@ -576,11 +593,9 @@ __device__ __forceinline__ int walk(const DScene& sc, WalkState& w, Hit& cur, bo
                 bool found = mesh_closest_linear(mesh, w.ray, &t, &slot);
                 mesh_result(mesh, nd, i, w.ray, found, t, mesh.tris_orig + slot, slot, &cur);
             } else {
-                if (trav_begin(mesh, w.ray, st, ts)) {
-                    status = kWalkMesh;
-                    break;
-                }
-                mesh_result(mesh, nd, i, w.ray, false, 0.0f, nullptr, 0u, &cur);
+                // every lane stops here together, whether or not its ray can reach the mesh
+                status = kWalkMesh;
+                break;
             }
         } else if (type == 3u) {
             DNode nd;
@@ -605,6 +620,20 @@ __device__ __forceinline__ int walk(const DScene& sc, WalkState& w, Hit& cur, bo
     w.open = open;
     w.depth = depth;
     return status;
+}
+
+// The mesh of the node the walk stopped at.
+__device__ __forceinline__ const DMesh& walk_mesh(const DScene& sc, const WalkState& w) {
+    return sc.meshes[const_nodes(sc)[__builtin_amdgcn_readfirstlane(w.i)].mesh_id];
+}
+
+// A whole search, begun and run to its end by this lane.
+__device__ __forceinline__ void search_in_place(const DMesh& mesh, const Ray& ray, TravStack& st, TravState& ts) {
+    if (!trav_begin(mesh, ray, st, ts)) return;
+    while (!trav_done(ts)) {
+        while (trav_is_inner(ts)) trav_inner(ts, ray, st);
+        if (!trav_done(ts)) trav_leaf(ts, ray, st);
+    }
 }
 
 // The result of the mesh node the walk stopped at, from a finished search.
@@ -634,11 +663,8 @@ __device__ __forceinline__ void scene_trace(const DScene& sc, Ray ray, bool brut
     cur.uv = mk2(0, 0);
     walk_begin(w, ray);
     bool resume = false;
-    while (walk(sc, w, cur, resume, brute, st, ts) == kWalkMesh) {
-        while (!trav_done(ts)) {
-            while (trav_is_inner(ts)) trav_inner(ts, w.ray, st);
-            if (!trav_done(ts)) trav_leaf(ts, w.ray, st);
-        }
+    while (walk(sc, w, cur, resume, brute, st) == kWalkMesh) {
+        search_in_place(walk_mesh(sc, w), w.ray, st, ts);
         walk_mesh_result(sc, w, ts, &cur);
         resume = true;
     }

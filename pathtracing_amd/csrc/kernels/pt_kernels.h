@@ -21,15 +21,16 @@ namespace ptk {
 struct Workspace {
     float4* queue[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     uint32_t* wave_counts[2] = {nullptr, nullptr};
-    // BVH search requests of the current / previous round and their per-region counts;
-    // results[k] = result of a ray's k-th search of the segment, indexed like a queue
-    float4* jobs[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-    uint32_t* job_counts[2] = {nullptr, nullptr};
+    // BVH search requests of the mesh node being searched (three rows per request,
+    // regions like a queue) with their per-region counts; results[m] = closest
+    // triangle of the scene's m-th mesh node for each ray, indexed like a queue
+    float4* jobs[3] = {nullptr, nullptr, nullptr};
+    uint32_t* job_counts = nullptr;
     float4* results[4] = {nullptr, nullptr, nullptr, nullptr};
     float* contrib = nullptr;    // 3 floats per path of the batch: its final colour
     uint64_t capacity_paths = 0; // records each queue array holds
     uint64_t contrib_paths = 0;  // paths the contribution buffer holds
-    uint64_t* ray_total = nullptr; // device-side running sum of traced rays
+    uint64_t* ray_total = nullptr; // device-side running sums: [0] traced rays, [1] BVH searches
     // Trace kernels run a persistent grid of `persistent_blocks` blocks; `spill`
     // holds one column of spill_dwords() dwords per thread of that grid.
     uint32_t* spill = nullptr;
@@ -41,7 +42,7 @@ uint32_t segment_blocks_per_cu(); // resident blocks per compute unit the trace 
 uint32_t queue_region_capacity(uint64_t paths, uint32_t waves);
 constexpr uint32_t kTraceBlock = 256;
 
-constexpr int kMaxDeferred = 4; // BVH searches per ray and segment that go through the search kernel
+constexpr int kMaxDeferred = 4; // mesh nodes of a scene whose searches go through the search kernel
 
 struct BatchGeometry {
     uint32_t x0, y0, w, h; // pixel rectangle, camera space
@@ -52,12 +53,13 @@ struct BatchGeometry {
 // Runs samples [sample_first, sample_first + sample_count) of every pixel of the
 // rectangle and adds their colours, in sample order, into d_accum (camera-space
 // layout, (x + y*W)*3).
-// `segment_events`: when non-null, a pair of events (start, stop) is created and
-// recorded around every path-segment kernel launch and appended to the vector.
+// `targets`: the scene graph's mesh nodes in array order.
+// `search_events`: when non-null, a pair of events (start, stop) is created and
+// recorded around every search_kernel launch and appended to the vector.
 hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeometry& geo, uint64_t seed,
                         uint64_t sample_first, uint32_t sample_count, uint32_t trace_depth, bool brute,
-                        uint32_t mesh_nodes, Workspace& ws, float* d_accum, hipStream_t stream,
-                        std::vector<hipEvent_t>* segment_events);
+                        const std::vector<MeshTarget>& targets, Workspace& ws, float* d_accum, hipStream_t stream,
+                        std::vector<hipEvent_t>* search_events);
 
 hipError_t resolve_image(const float* d_accum, uint32_t width, uint32_t height, float scale, float* d_out,
                          hipStream_t stream);

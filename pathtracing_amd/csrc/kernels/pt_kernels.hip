@@ -1,11 +1,12 @@
 // gfx950 kernels of the wavefront path tracer.
 //
 // One batch = some consecutive samples of every pixel of a rectangle.  Per batch:
-//   segment_kernel x D   one path segment per live path (the first launch also
-//                        generates the camera rays): scene trace + material
-//                        sampling; survivors go to the wave's region of the other
-//                        queue, finished paths store their colour into the
-//                        contribution buffer
+//   camera_kernel        the batch's camera rays
+//   per path segment:    jobs_kernel + search_kernel for each mesh node of the
+//                        scene graph (closest triangle per ray), then walk_kernel:
+//                        scene-graph walk + material sampling; survivors go to the
+//                        wave's region of the other queue, finished paths store
+//                        their colour into the contribution buffer
 //   accumulate_kernel    per pixel, adds the batch's contributions in sample order
 // (work_group.rs:26-69 is the per-pixel loop this replaces).
 #include <hip/hip_runtime.h>
@@ -69,47 +70,136 @@ uint32_t segment_blocks_per_cu() { return kGridBlocksPerCu; }
 // Device pointers of one path segment.  Every array is cut into `regions` regions
 // of `cap` records; region r is owned by one wave per kernel (wave w of a launch
 // takes regions w, w + W, ...), so nothing here needs atomics:
-//   rays      this segment's rays            (source,min) (direction,path id) (multiplier,draw counter)
-//   next      rays of the next segment, appended per region, lengths in next_counts
-//   jobs      BVH searches requested by the walk kernel of this round
-//             (object-space source,min) (direction,max) (ray index, mesh id, search number, -)
-//   prev_jobs the previous round's requests = the rays the walk kernel of this round continues
-//   res[k]    result of a ray's k-th search, indexed like `rays`: (t, found, leaf slot, triangle index)
+//   rays    this segment's rays            (source,min) (direction,path id) (multiplier,draw counter)
+//   next    rays of the next segment, appended per region, lengths in next_counts
+//   res[m]  closest triangle of the scene's m-th mesh node for each ray, indexed like
+//           `rays`: (t, found, leaf slot, triangle index)
 struct SegmentBuffers {
     float4 *ray_a, *ray_b, *ray_c;
-    const uint32_t* ray_counts;
+    uint32_t* ray_counts;
     float4 *next_a, *next_b, *next_c;
     uint32_t* next_counts;
-    float4 *job_a, *job_b, *job_c;
-    uint32_t* job_counts;
-    const float4* prev_job_c;
-    const uint32_t* prev_job_counts;
     float4* res[kMaxDeferred];
 };
 
-// ---------------------------------------------------------------- walk kernel
-// Everything of a path segment (work_group.rs:29-47) except the BVH searches:
-// camera ray (first segment), scene-graph walk, material sampling, queueing of
-// the next segment's ray or the path's final colour.  A ray whose walk reaches a
-// mesh whose BVH must be searched is parked: the search is written as a job for
-// search_kernel and the ray is walked again from the start in the next round,
-// this time with the search's result at hand (the walk is deterministic, so the
-// second walk repeats the first bit for bit; re-walking a handful of cheap nodes
-// costs less than saving and restoring the walk's state).  `defer` = false (last
-// round) or more than kMaxDeferred searches on one ray: the search runs in place.
-#ifndef PT_WALK_OCCUPANCY
-#define PT_WALK_OCCUPANCY 3
-#endif
-template <bool FIRST>
-__global__ void __launch_bounds__(kBlock, PT_WALK_OCCUPANCY)
-walk_kernel(RenderParams p, uint32_t depth, uint32_t round, uint32_t defer, SegmentBuffers b, uint32_t cap,
-            uint32_t regions, float* contrib, unsigned long long* ray_total, uint32_t* spill, uint32_t spill_threads) {
-    __shared__ int32_t lds_stack[kLdsStack * kBlock];
+// -------------------------------------------------------------- camera kernel
+// Camera::get_ray (camera.rs:51-83) for every path of the batch: path slot ->
+// (sample, pixel), the first draws of the path's random stream, the ray into the
+// wave's region of the first segment's queue.  64-slot chunks (8x8 pixels of one
+// sample) go round-robin over the regions.
+__global__ void __launch_bounds__(kBlock)
+camera_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions) {
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
     const uint32_t waves = (gridDim.x * kBlock) >> 6;
     const uint64_t total = (uint64_t)p.sample_count * p.geo.npp;
+    const uint32_t chunks_total = (uint32_t)((total + 63u) >> 6);
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    for (uint32_t r = wave; r < regions; r += waves) {
+        const size_t base = (size_t)r * cap;
+        uint32_t out_pos = 0u;
+        for (uint32_t chunk = r; chunk < chunks_total; chunk += regions) {
+            uint64_t slot = (uint64_t)chunk * 64u + lane;
+            bool have = false;
+            Ray ray;
+            uint32_t rng_counter = 0;
+            if (slot < total) {
+                uint32_t s_local = (uint32_t)(slot / p.geo.npp);
+                uint32_t q = (uint32_t)(slot % p.geo.npp);
+                uint32_t x, y;
+                path_slot_to_pixel(p.geo, q, &x, &y, &have);
+                if (have) {
+                    Rng rng;
+                    rng.key = stream_key(p.seed, stream_id(p.sample_first + s_local, (uint64_t)x + (uint64_t)y * p.cam.width));
+                    rng.counter = 0;
+                    ray = camera_get_ray(p.cam, x, y, rng);
+                    rng_counter = rng.counter;
+                }
+            }
+            unsigned long long mask = __ballot(have);
+            if (have) {
+                size_t o = base + out_pos + (uint32_t)__popcll(mask & lane_lt);
+                b.ray_a[o] = make_float4(ray.source.x, ray.source.y, ray.source.z, ray.min);
+                b.ray_b[o] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, __uint_as_float((uint32_t)slot));
+                b.ray_c[o] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng_counter));
+            }
+            out_pos += (uint32_t)__popcll(mask);
+        }
+        if (lane == 0u) b.ray_counts[r] = out_pos;
+    }
+}
+
+// ---------------------------------------------------------------- jobs kernel
+// Prepares the BVH searches of one mesh node for every ray of the segment: takes
+// the ray through the transform nodes above the mesh (the arithmetic the walk
+// kernel repeats later, transform.rs:45-48), rejects rays that cannot reach the
+// mesh and appends the others to the job list of the wave's region:
+//   (object-space source,min) (direction,max) (ray index, mesh id, -, -)
+// A rejected ray gets its "no triangle" result right here.
+__global__ void __launch_bounds__(kBlock)
+jobs_kernel(DScene scene, MeshTarget target, const float4* __restrict__ ray_a, const float4* __restrict__ ray_b,
+            const uint32_t* __restrict__ ray_counts, float4* job_a, float4* job_b, float4* job_c, uint32_t* job_counts,
+            float4* res, unsigned long long* search_total, uint32_t cap, uint32_t regions) {
+    const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+    const uint32_t waves = (gridDim.x * kBlock) >> 6;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    unsigned long long listed = 0;
+    ConstNodePtr nodes = const_nodes(scene);
+    const DMesh& mesh = scene.meshes[target.mesh_id];
+    for (uint32_t r = wave; r < regions; r += waves) {
+        const size_t base = (size_t)r * cap;
+        const uint32_t n_items = ray_counts[r];
+        uint32_t job_pos = 0u;
+        for (uint32_t first = 0; first < n_items; first += 64u) {
+            const uint32_t item = first + lane;
+            const bool have = item < n_items;
+            bool need = false;
+            Ray ray;
+            if (have) {
+                float4 ra = ray_a[base + item], rb = ray_b[base + item];
+                ray.source = mk3(ra.x, ra.y, ra.z);
+                ray.min = ra.w;
+                ray.direction = mk3(rb.x, rb.y, rb.z);
+                ray.max = kF32Max;
+                for (uint32_t c = 0; c < target.chain_len; c++) ray = transform_ray_c(nodes[target.chain[c]], ray);
+                need = trav_reaches(mesh, ray);
+                if (!need) res[base + item] = make_float4(f32_inf(), __uint_as_float(0u), __uint_as_float(0u), __uint_as_float(0xFFFFFFFFu));
+            }
+            unsigned long long mask = __ballot(need);
+            if (need) {
+                size_t j = base + job_pos + (uint32_t)__popcll(mask & lane_lt);
+                job_a[j] = make_float4(ray.source.x, ray.source.y, ray.source.z, ray.min);
+                job_b[j] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, ray.max);
+                job_c[j] = make_float4(__uint_as_float(item), __uint_as_float(target.mesh_id), 0.0f, 0.0f);
+            }
+            job_pos += (uint32_t)__popcll(mask);
+        }
+        if (lane == 0u) job_counts[r] = job_pos;
+        listed += job_pos;
+    }
+    if (lane == 0u && listed) atomicAdd(search_total, listed);
+}
+
+// ---------------------------------------------------------------- walk kernel
+// Everything of a path segment (work_group.rs:29-47) except the BVH searches,
+// which have run before it: scene-graph walk with the closest triangle of every
+// mesh node read from res[], material sampling, queueing of the next segment's
+// ray or the path's final colour.  Scenes with more than kMaxDeferred mesh nodes,
+// and the linear-scan mode, search the remaining meshes in place.
+#ifndef PT_WALK_OCCUPANCY
+#define PT_WALK_OCCUPANCY 3
+#endif
+__global__ void __launch_bounds__(kBlock, PT_WALK_OCCUPANCY)
+walk_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, uint32_t cap, uint32_t regions, float* contrib,
+            unsigned long long* ray_total, uint32_t* spill, uint32_t spill_threads) {
+    __shared__ int32_t lds_stack[kLdsStack * kBlock];
+    const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+    const uint32_t waves = (gridDim.x * kBlock) >> 6;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     const bool brute = p.brute != 0u;
     TravStack st = make_stack(lds_stack, spill, spill_threads);
@@ -117,64 +207,25 @@ walk_kernel(RenderParams p, uint32_t depth, uint32_t round, uint32_t defer, Segm
 
     for (uint32_t r = wave; r < regions; r += waves) {
         const size_t base = (size_t)r * cap;
-        uint32_t n_items;
-        if (round > 0u) {
-            n_items = b.prev_job_counts[r];
-        } else if (FIRST) {
-            uint32_t chunks_total = (uint32_t)((total + 63u) >> 6);
-            n_items = r < chunks_total ? ((chunks_total - r + regions - 1u) / regions) * 64u : 0u;
-        } else {
-            n_items = b.ray_counts[r];
-        }
-        uint32_t out_pos = round > 0u ? b.next_counts[r] : 0u;
-        uint32_t job_pos = 0u;
+        const uint32_t n_items = b.ray_counts[r];
+        uint32_t out_pos = 0u;
         for (uint32_t first = 0; first < n_items; first += 64u) {
             const uint32_t item = first + lane;
-            bool have = item < n_items;
-            uint32_t v = item;
-            if (have && round > 0u) v = __float_as_uint(b.prev_job_c[base + item].x);
-            Ray ray;
-            uint32_t path = 0, rng_counter = 0;
-            V3 mult = mk3(1.0f, 1.0f, 1.0f);
-            if (have) {
-                if (FIRST && round == 0u) {
-                    uint64_t slot = ((uint64_t)(v >> 6) * regions + r) * 64u + (v & 63u);
-                    have = false;
-                    if (slot < total) {
-                        uint32_t s_local = (uint32_t)(slot / p.geo.npp);
-                        uint32_t q = (uint32_t)(slot % p.geo.npp);
-                        uint32_t x, y;
-                        bool valid;
-                        path_slot_to_pixel(p.geo, q, &x, &y, &valid);
-                        if (valid) {
-                            Rng rng;
-                            rng.key = stream_key(p.seed, stream_id(p.sample_first + s_local,
-                                                                   (uint64_t)x + (uint64_t)y * p.cam.width));
-                            rng.counter = 0;
-                            ray = camera_get_ray(p.cam, x, y, rng);
-                            rng_counter = rng.counter;
-                            path = (uint32_t)slot;
-                            have = true;
-                        }
-                    }
-                } else {
-                    float4 ra = b.ray_a[base + v], rb = b.ray_b[base + v], rc = b.ray_c[base + v];
-                    ray.source = mk3(ra.x, ra.y, ra.z);
-                    ray.min = ra.w;
-                    ray.direction = mk3(rb.x, rb.y, rb.z);
-                    ray.max = kF32Max;
-                    path = __float_as_uint(rb.w);
-                    mult = mk3(rc.x, rc.y, rc.z);
-                    rng_counter = __float_as_uint(rc.w);
-                }
-            }
-            bool emit = false, park = false;
+            const bool have = item < n_items;
+            bool emit = false;
             Ray nray;
             V3 nmult = mk3(0, 0, 0);
-            TravState ts;
-            WalkState w;
-            uint32_t searches = 0; // BVH searches met so far on this walk
+            uint32_t path = 0, rng_counter = 0;
             if (have) {
+                float4 ra = b.ray_a[base + item], rb = b.ray_b[base + item], rc = b.ray_c[base + item];
+                Ray ray;
+                ray.source = mk3(ra.x, ra.y, ra.z);
+                ray.min = ra.w;
+                ray.direction = mk3(rb.x, rb.y, rb.z);
+                ray.max = kF32Max;
+                path = __float_as_uint(rb.w);
+                V3 mult = mk3(rc.x, rc.y, rc.z);
+                rng_counter = __float_as_uint(rc.w);
                 Hit cur;
                 cur.hit = 0u;
                 cur.hit_inside = 0u;
@@ -185,100 +236,69 @@ walk_kernel(RenderParams p, uint32_t depth, uint32_t round, uint32_t defer, Segm
                 cur.point = mk3(0, 0, 0);
                 cur.normal = mk3(0, 0, 0);
                 cur.uv = mk2(0, 0);
+                WalkState w;
+                TravState ts;
                 walk_begin(w, ray);
                 bool resume = false;
-                while (walk(p.scene, w, cur, resume, brute, st, ts) == kWalkMesh) {
-                    if (searches < round && searches < (uint32_t)kMaxDeferred) {
-                        // searched in an earlier round
-                        float4 res = b.res[searches][base + v];
+                while (walk(p.scene, w, cur, resume, brute, st) == kWalkMesh) {
+                    const uint32_t m = const_nodes(p.scene)[__builtin_amdgcn_readfirstlane(w.i)].mesh_ordinal;
+                    if (m < (uint32_t)kMaxDeferred) {
+                        float4 res = b.res[m][base + item];
                         ts.tbest = res.x;
                         ts.found = __float_as_uint(res.y);
                         ts.best_slot = __float_as_uint(res.z);
                         ts.best_orig = __float_as_uint(res.w);
-                        ts.tris = nullptr; // walk_mesh_result takes the triangle array from the mesh
-                    } else if (defer != 0u && searches < (uint32_t)kMaxDeferred) {
-                        park = true;
-                        break;
                     } else {
-                        while (!trav_done(ts)) {
-                            while (trav_is_inner(ts)) trav_inner(ts, w.ray, st);
-                            if (!trav_done(ts)) trav_leaf(ts, w.ray, st);
-                        }
+                        search_in_place(walk_mesh(p.scene, w), w.ray, st, ts);
                     }
                     walk_mesh_result(p.scene, w, ts, &cur);
-                    searches++;
                     resume = true;
                 }
-                if (!park) {
-                    // the segment's trace is complete: work_group.rs:31-47
-                    traced++;
-                    V3 color = mk3(0, 0, 0);
-                    bool finished = true;
-                    if (cur.hit) {
-                        uint32_t s_local = path / p.geo.npp, q = path % p.geo.npp;
-                        uint32_t x, y;
-                        bool valid;
-                        path_slot_to_pixel(p.geo, q, &x, &y, &valid);
-                        Rng rng;
-                        rng.key = stream_key(p.seed, stream_id(p.sample_first + s_local, (uint64_t)x + (uint64_t)y * p.cam.width));
-                        rng.counter = rng_counter;
-                        V3 av, dir;
-                        bool is_color =
-                            material_get_color(p.scene.materials[cur.material_id], w.ray.direction, cur, rng, &av, &dir);
-                        rng_counter = rng.counter;
-                        if (is_color) {
-                            color = mult * av;
-                        } else if (depth + 1u < p.trace_depth) {
-                            nray.source = cur.point + dir * kEpsilon;
-                            nray.direction = dir;
-                            nray.min = kEpsilon;
-                            nray.max = kF32Max;
-                            nmult = mult * av;
-                            finished = false;
-                            emit = true;
-                        }
-                    }
-                    if (finished) {
-                        float* dst = contrib + (size_t)path * 3;
-                        dst[0] = color.x;
-                        dst[1] = color.y;
-                        dst[2] = color.z;
+                // the segment's trace is complete: work_group.rs:31-47
+                traced++;
+                V3 color = mk3(0, 0, 0);
+                bool finished = true;
+                if (cur.hit) {
+                    uint32_t s_local = path / p.geo.npp, q = path % p.geo.npp;
+                    uint32_t x, y;
+                    bool valid;
+                    path_slot_to_pixel(p.geo, q, &x, &y, &valid);
+                    Rng rng;
+                    rng.key = stream_key(p.seed, stream_id(p.sample_first + s_local, (uint64_t)x + (uint64_t)y * p.cam.width));
+                    rng.counter = rng_counter;
+                    V3 av, dir;
+                    bool is_color = material_get_color(p.scene.materials[cur.material_id], w.ray.direction, cur, rng, &av, &dir);
+                    rng_counter = rng.counter;
+                    if (is_color) {
+                        color = mult * av;
+                    } else if (depth + 1u < p.trace_depth) {
+                        nray.source = cur.point + dir * kEpsilon;
+                        nray.direction = dir;
+                        nray.min = kEpsilon;
+                        nray.max = kF32Max;
+                        nmult = mult * av;
+                        finished = false;
+                        emit = true;
                     }
                 }
-            }
-            // parked rays: the search request, and (first segment) the generated ray itself
-            unsigned long long park_mask = __ballot(park);
-            if (park_mask != 0ull) {
-                if (park) {
-                    size_t j = base + job_pos + (uint32_t)__popcll(park_mask & lane_lt);
-                    const uint32_t mesh_id = const_nodes(p.scene)[__builtin_amdgcn_readfirstlane(w.i)].mesh_id;
-                    b.job_a[j] = make_float4(w.ray.source.x, w.ray.source.y, w.ray.source.z, w.ray.min);
-                    b.job_b[j] = make_float4(w.ray.direction.x, w.ray.direction.y, w.ray.direction.z, w.ray.max);
-                    b.job_c[j] = make_float4(__uint_as_float(v), __uint_as_float(mesh_id), __uint_as_float(searches), 0.0f);
-                    if (FIRST && round == 0u) {
-                        b.ray_a[base + v] = make_float4(ray.source.x, ray.source.y, ray.source.z, ray.min);
-                        b.ray_b[base + v] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, __uint_as_float(path));
-                        b.ray_c[base + v] = make_float4(mult.x, mult.y, mult.z, __uint_as_float(rng_counter));
-                    }
+                if (finished) {
+                    float* dst = contrib + (size_t)path * 3;
+                    dst[0] = color.x;
+                    dst[1] = color.y;
+                    dst[2] = color.z;
                 }
-                job_pos += (uint32_t)__popcll(park_mask);
             }
             // surviving paths go to this region of the next segment's queue
             unsigned long long emit_mask = __ballot(emit);
-            if (emit_mask != 0ull) {
-                if (emit) {
-                    size_t slot = base + out_pos + (uint32_t)__popcll(emit_mask & lane_lt);
-                    b.next_a[slot] = make_float4(nray.source.x, nray.source.y, nray.source.z, nray.min);
-                    b.next_b[slot] = make_float4(nray.direction.x, nray.direction.y, nray.direction.z, __uint_as_float(path));
-                    b.next_c[slot] = make_float4(nmult.x, nmult.y, nmult.z, __uint_as_float(rng_counter));
-                }
-                out_pos += (uint32_t)__popcll(emit_mask);
+            if (emit) {
+                size_t slot = base + out_pos + (uint32_t)__popcll(emit_mask & lane_lt);
+                b.next_a[slot] = make_float4(nray.source.x, nray.source.y, nray.source.z, nray.min);
+                b.next_b[slot] = make_float4(nray.direction.x, nray.direction.y, nray.direction.z, __uint_as_float(path));
+                b.next_c[slot] = make_float4(nmult.x, nmult.y, nmult.z, __uint_as_float(rng_counter));
             }
+            out_pos += (uint32_t)__popcll(emit_mask);
         }
-        if (lane == 0u) {
-            if (b.next_counts) b.next_counts[r] = out_pos;
-            if (b.job_counts) b.job_counts[r] = job_pos;
-        }
+        if (lane == 0u) b.next_counts[r] = out_pos;
     }
     unsigned long long traced_total = 0;
     {
@@ -290,15 +310,15 @@ walk_kernel(RenderParams p, uint32_t depth, uint32_t round, uint32_t defer, Segm
 }
 
 // -------------------------------------------------------------- search kernel
-// The BVH searches requested by walk_kernel.  This is where the time goes, so
-// the kernel carries nothing but the search: ~64 registers per lane, 8 waves per
+// The BVH searches listed by jobs_kernel.  This is where the time goes, so the
+// kernel carries nothing but the search: ~64 registers per lane, 8 waves per
 // SIMD to cover the latency of the dependent node fetches.  Lanes do not wait for
 // the slowest search of their wave: each lane is a small state machine and the
 // wave hands idle lanes new jobs whenever kRefill searches have finished (search
 // lengths differ by an order of magnitude between neighbouring rays).
 __global__ void __launch_bounds__(kBlock, PT_SEARCH_OCCUPANCY)
 search_kernel(const DMesh* __restrict__ meshes, const float4* __restrict__ job_a, const float4* __restrict__ job_b,
-              const float4* __restrict__ job_c, const uint32_t* __restrict__ job_counts, SegmentBuffers b, uint32_t cap,
+              const float4* __restrict__ job_c, const uint32_t* __restrict__ job_counts, float4* res, uint32_t cap,
               uint32_t regions, uint32_t* spill, uint32_t spill_threads) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
@@ -337,10 +357,10 @@ search_kernel(const DMesh* __restrict__ meshes, const float4* __restrict__ job_a
                 ray.min = ja.w;
                 ray.direction = mk3(jb.x, jb.y, jb.z);
                 ray.max = jb.w;
-                uint32_t v = __float_as_uint(jc.x), mesh_id = __float_as_uint(jc.y), k = __float_as_uint(jc.z);
-                res_out = b.res[k] + ((size_t)region * cap + v);
+                uint32_t v = __float_as_uint(jc.x), mesh_id = __float_as_uint(jc.y);
+                res_out = res + ((size_t)region * cap + v);
                 const DMesh& mesh = meshes[mesh_id];
-                // the walk kernel has already checked the ray against the mesh bounds
+                // the jobs kernel has already checked the ray against the mesh bounds
                 ts.inv = mk3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
                 ts.ray_limit = (ray.max == ray.max) ? ray.max : f32_inf();
                 ts.nodes = mesh.nodes;
@@ -519,8 +539,8 @@ static inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kBlock - 
 
 hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeometry& geo, uint64_t seed,
                         uint64_t sample_first, uint32_t sample_count, uint32_t trace_depth, bool brute,
-                        uint32_t mesh_nodes, Workspace& ws, float* d_accum, hipStream_t stream,
-                        std::vector<hipEvent_t>* segment_events) {
+                        const std::vector<MeshTarget>& targets, Workspace& ws, float* d_accum, hipStream_t stream,
+                        std::vector<hipEvent_t>* search_events) {
     RenderParams p;
     p.scene = scene;
     p.cam = cam;
@@ -536,53 +556,49 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
     const uint32_t regions = ws.persistent_blocks * (kBlock / 64);
     const uint32_t cap = queue_region_capacity(total, regions);
     if ((uint64_t)cap * regions > ws.capacity_paths || total > ws.contrib_paths) return hipErrorInvalidValue;
-    // rounds of (walk, search) per segment: one per mesh a ray may have to search, at most kMaxDeferred;
-    // the linear-scan mode never defers
-    const uint32_t rounds = brute ? 0u : std::min<uint32_t>(mesh_nodes, (uint32_t)kMaxDeferred);
+    // mesh nodes searched ahead of the walk; the linear-scan mode searches nothing ahead
+    const uint32_t searched = brute ? 0u : std::min<uint32_t>((uint32_t)targets.size(), (uint32_t)kMaxDeferred);
+    for (uint32_t m = 0; m < searched; m++)
+        if (!ws.results[m]) return hipErrorInvalidValue;
     const uint32_t spill_threads = ws.persistent_blocks * kBlock;
     unsigned long long* rt = reinterpret_cast<unsigned long long*>(ws.ray_total);
     hipError_t e;
+    auto buffers = [&](int in) {
+        int out = in ^ 1;
+        SegmentBuffers b;
+        b.ray_a = ws.queue[in][0];
+        b.ray_b = ws.queue[in][1];
+        b.ray_c = ws.queue[in][2];
+        b.ray_counts = ws.wave_counts[in];
+        b.next_a = ws.queue[out][0];
+        b.next_b = ws.queue[out][1];
+        b.next_c = ws.queue[out][2];
+        b.next_counts = ws.wave_counts[out];
+        for (int k = 0; k < kMaxDeferred; k++) b.res[k] = ws.results[k];
+        return b;
+    };
+    camera_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, buffers(0), cap, regions);
     for (uint32_t d = 0; d < trace_depth; d++) {
-        int in = d & 1, out = in ^ 1;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (segment_events) {
-            if ((e = hipEventCreate(&e0)) != hipSuccess) return e;
-            if ((e = hipEventCreate(&e1)) != hipSuccess) return e;
-            segment_events->push_back(e0);
-            segment_events->push_back(e1);
-            if ((e = hipEventRecord(e0, stream)) != hipSuccess) return e;
+        SegmentBuffers b = buffers((int)(d & 1u));
+        for (uint32_t m = 0; m < searched; m++) {
+            jobs_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(scene, targets[m], b.ray_a, b.ray_b, b.ray_counts,
+                                                                     ws.jobs[0], ws.jobs[1], ws.jobs[2], ws.job_counts,
+                                                                     ws.results[m], rt + 1, cap, regions);
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (search_events) {
+                if ((e = hipEventCreate(&e0)) != hipSuccess) return e;
+                search_events->push_back(e0);
+                if ((e = hipEventCreate(&e1)) != hipSuccess) return e;
+                search_events->push_back(e1);
+                if ((e = hipEventRecord(e0, stream)) != hipSuccess) return e;
+            }
+            search_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(scene.meshes, ws.jobs[0], ws.jobs[1], ws.jobs[2],
+                                                                      ws.job_counts, ws.results[m], cap, regions, ws.spill,
+                                                                      spill_threads);
+            if (search_events && (e = hipEventRecord(e1, stream)) != hipSuccess) return e;
         }
-        for (uint32_t r = 0; r <= rounds; r++) {
-            int jcur = r & 1, jprev = jcur ^ 1;
-            SegmentBuffers b;
-            b.ray_a = ws.queue[in][0];
-            b.ray_b = ws.queue[in][1];
-            b.ray_c = ws.queue[in][2];
-            b.ray_counts = ws.wave_counts[in];
-            b.next_a = ws.queue[out][0];
-            b.next_b = ws.queue[out][1];
-            b.next_c = ws.queue[out][2];
-            b.next_counts = ws.wave_counts[out];
-            b.job_a = ws.jobs[jcur][0];
-            b.job_b = ws.jobs[jcur][1];
-            b.job_c = ws.jobs[jcur][2];
-            b.job_counts = ws.job_counts[jcur];
-            b.prev_job_c = ws.jobs[jprev][2];
-            b.prev_job_counts = ws.job_counts[jprev];
-            for (int k = 0; k < kMaxDeferred; k++) b.res[k] = ws.results[k];
-            uint32_t defer = r < rounds ? 1u : 0u;
-            if (d == 0)
-                walk_kernel<true><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, r, defer, b, cap, regions, ws.contrib,
-                                                                               rt, ws.spill, spill_threads);
-            else
-                walk_kernel<false><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, r, defer, b, cap, regions,
-                                                                                ws.contrib, rt, ws.spill, spill_threads);
-            if (defer)
-                search_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(scene.meshes, b.job_a, b.job_b, b.job_c,
-                                                                          b.job_counts, b, cap, regions, ws.spill,
-                                                                          spill_threads);
-        }
-        if (segment_events && (e = hipEventRecord(e1, stream)) != hipSuccess) return e;
+        walk_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, b, cap, regions, ws.contrib, rt, ws.spill,
+                                                                 spill_threads);
     }
     accumulate_kernel<<<blocks_for(geo.npp), kBlock, 0, stream>>>(geo, cam.width, sample_count, ws.contrib, d_accum);
     return hipGetLastError();

@@ -65,6 +65,8 @@ struct DNode {
     uint32_t mesh_id;
     uint32_t parent;  // nearest enclosing collection / transform node, or 0xFFFFFFFF
     uint32_t depth;   // number of enclosing collection / transform nodes
+    uint32_t mesh_ordinal; // MESH: how many mesh nodes precede this one in the array
+    uint32_t pad0;
     // TRANSFORM (transform.rs:33-40 plus the per-ray normal_matrix() of ray.rs:29)
     M4 matrix, matrix_inverse;
     M3 normal_matrix, inverse_normal_matrix;
@@ -89,6 +91,17 @@ struct DMaterial {
     float roughness_sqr; // pbr.rs:94
 };
 
+constexpr int kMaxGraphDepth = 8; // nested collection/transform frames the kernels keep
+
+// One mesh node as a target of BVH searches: the transform nodes above it,
+// outermost first, take a world-space ray into the mesh's space.
+struct MeshTarget {
+    uint32_t node_index;
+    uint32_t mesh_id;
+    uint32_t chain_len;
+    uint32_t chain[kMaxGraphDepth];
+};
+
 struct DScene {
     const DNode* nodes;
     uint32_t node_count;
@@ -96,8 +109,6 @@ struct DScene {
     const DMaterial* materials;
     uint32_t mesh_count, material_count;
 };
-
-constexpr int kMaxGraphDepth = 8; // nested collection/transform frames the kernels keep
 
 // Camera::get_ray inputs with the per-task constants precomputed on the host.
 struct DCamera {

@@ -14,12 +14,18 @@ from tests import oracle_binding as ob
 
 pytestmark = pytest.mark.gpu
 
-SCENES = ["./scene0.json", "./simple_scene.json", "./scene.json"]
+SCENES = ["./scene0.json", "./simple_scene.json", "./scene.json", "./nested.json"]
 
 
 @pytest.fixture(scope="module", params=SCENES)
-def pair(request, oracle):
-    scene = P.Scene.load(H.SCENE_DATA, request.param)
+def pair(request, oracle, tmp_path_factory):
+    root = H.SCENE_DATA
+    if request.param == "./nested.json":
+        # six mesh nodes: more than the search kernel handles ahead of the walk, so
+        # the in-place search of the walk kernel is covered as well
+        root = str(tmp_path_factory.mktemp("nested") / "scene")
+        H.write_nested_scene(root)
+    scene = P.Scene.load(root, request.param)
     gpu = P.HipRenderer.init(scene, 0)
     cpu = oracle.scene(scene.desc_pointer)
     yield request.param, gpu, cpu

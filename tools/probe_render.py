@@ -14,4 +14,4 @@ for it in (1, 8, 64):
         t0 = time.time(); img = r.render(task, P.RenderOpts(seed=0, profile=(rep == 1))); dt = time.time() - t0
         s = r.last_stats
         print(f'iters={it} wall={dt:.3f}s render_ms={s.render_ms:.1f} rays={s.rays} Mrays/s={s.rays / s.render_ms / 1e3:.1f} '
-              f'seg_ms={s.segment_kernel_ms:.1f} launches={s.segment_kernel_launches} mean={img.mean():.4f}', flush=True)
+              f'search_ms={s.search_kernel_ms:.1f} launches={s.search_kernel_launches} searches={s.searches} mean={img.mean():.4f}', flush=True)
