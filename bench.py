@@ -25,6 +25,7 @@ import numpy as np  # noqa: E402
 
 import pathtracing_amd as P  # noqa: E402  (loads the HIP library; fails loudly if it is missing)
 from pathtracing_amd import synth  # noqa: E402
+from pathtracing_amd.distributed import render_sharded, shard_opts  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 64, 8
@@ -91,6 +92,13 @@ def bytes_per_ray(s) -> float:
             + 24.0 / s["mean_path_length"])
 
 
+def search_bytes_per_ray(s, searches_per_ray: float) -> float:
+    """The share of bytes_per_ray() that the BVH search kernel moves: the box and
+    triangle tests of a ray, and per search the 48 B request it reads and the
+    16 B result it writes."""
+    return 32.0 * s["n_box"] + 36.0 * s["n_tri"] + 64.0 * searches_per_ray
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,17 +138,21 @@ def main():
     accum = torch.zeros(HEIGHT * WIDTH * 3, dtype=torch.float32, device=f"cuda:{device}")
     out = torch.empty_like(accum)
     stream = torch.cuda.current_stream().cuda_stream
-    opts = P.RenderOpts(seed=0, sample_offset=rank * SPP)
+    # weak scaling: the frame gets SPP samples per GPU; rank r renders samples [r*SPP, (r+1)*SPP)
+    frame = P.RenderTask(scene=task.scene, scene_md5=task.scene_md5, camera=task.camera,
+                         config=P.Config(trace_depth=DEPTH, iterations=SPP * world))
+    last = {}
 
-    def step(profile=False):
+    def step():
         accum.zero_()
-        o = P.RenderOpts(seed=opts.seed, sample_offset=opts.sample_offset, profile=profile)
-        st = renderer.render_accumulate_device(task, o, accum.data_ptr(), stream, want_stats=True)
-        if multi:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+
+        def render(sub, opts, buf):
+            last["stats"] = renderer.render_accumulate_device(sub, opts, buf.data_ptr(), stream, want_stats=True)
+
+        render_sharded(render, frame, accum, mode="samples", seed=0)  # renders, then RCCL reduce(sum) onto rank 0
         if rank == 0:
             P._native.check(P._native.lib.pt_resolve_device(accum.data_ptr(), WIDTH, HEIGHT, SPP * world, out.data_ptr(), stream))
-        return st
+        return last["stats"]
 
     def fence():
         if multi:
@@ -166,25 +178,35 @@ def main():
 
     result = None
     if rank == 0:
-        # one more, untimed, step with per-launch events on the render stream
-        prof = step(profile=True)
-        torch.cuda.synchronize()
         frame_mean = float(out.mean().item())
+        # one more, untimed, render of this rank's share (no collective: the other ranks
+        # have left the loop) with events around every search_kernel launch
+        sub, o = shard_opts(frame, world, 0, "samples", seed=0)
+        o.profile = True
+        prof = renderer.render_accumulate_device(sub, o, accum.data_ptr(), stream, want_stats=True)
+        torch.cuda.synchronize()
         if args.no_cpu_baseline:
             ref, bvh, stats = None, None, None
         else:
             ref, bvh, stats = cpu_legs(scene, task)
         roofline = None
-        if stats is not None and prof.segment_kernel_launches:
+        if stats is not None and prof.search_kernel_launches:
+            # dominant kernel: search_kernel (one launch per path segment and mesh node)
+            b_search = search_bytes_per_ray(stats, prof.searches / prof.rays)
+            launch_ms = prof.search_kernel_ms / prof.search_kernel_launches
+            rays_per_launch = prof.rays / prof.search_kernel_launches
+            achieved = b_search * rays_per_launch / (launch_ms * 1e-3) / 1e9
             b_ray = bytes_per_ray(stats)
-            launch_ms = prof.segment_kernel_ms / prof.segment_kernel_launches
-            rays_per_launch = prof.rays / prof.segment_kernel_launches
-            achieved = b_ray * rays_per_launch / (launch_ms * 1e-3) / 1e9
             roofline = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(), "kernel": "bounce_kernel",
-                "bytes_per_ray": b_ray, "rays_per_launch": rays_per_launch, "launch_ms": launch_ms,
-                "launches": int(prof.segment_kernel_launches), "ray_statistics": stats,
+                "traffic": measured_traffic(), "kernel": "search_kernel",
+                "bytes_per_ray": b_search, "rays_per_launch": rays_per_launch, "launch_ms": launch_ms,
+                "launches": int(prof.search_kernel_launches), "searches_per_ray": prof.searches / prof.rays,
+                "ray_statistics": stats,
+                # all kernels of the render against all algorithmic bytes of a path segment
+                "whole_render": {"bytes_per_ray": b_ray, "achieved": b_ray * prof.rays / (prof.render_ms * 1e-3) / 1e9,
+                                 "frac": b_ray * prof.rays / (prof.render_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "render_ms": prof.render_ms},
             }
         result = {
             "metric": "Mrays/s dragon 1080p 64spp", "value": rays / elapsed / 1e6, "unit": "Mrays/s",
@@ -193,7 +215,7 @@ def main():
             "config": {
                 "workload": f"dragon stand-in (871,200 triangles, torus-knot tube) in a textured box, {WIDTH}x{HEIGHT}, "
                             f"{SPP} samples per pixel per GPU, trace depth {DEPTH}",
-                "sharding": "sample range per GPU, RCCL reduce of the accumulation buffers" if multi else "single GPU",
+                "sharding": "sample range per GPU, RCCL reduce(sum) of the accumulation buffers onto rank 0" if multi else "single GPU",
                 "rays_per_step": rays // args.steps, "scene_setup_s": setup_s, "frame_mean": frame_mean,
             },
             "roofline": roofline, "cpu_baseline": ref, "cpu_baseline_bvh": bvh,

@@ -318,7 +318,7 @@ __device__ __forceinline__ bool all_finite(V3 v) {
 // State of one lane's search through a mesh's BVH.  The search must return what
 // the linear scan of mesh/mod.rs:57-62 returns: the smallest t, the lowest
 // triangle index among equal t.  It is cut into steps so that a wave can stop,
-// hand finished lanes new rays and go on (see bounce_kernel).
+// hand finished lanes new rays and go on (see search_kernel).
 struct TravState {
     const BvhNode* nodes;
     const LeafTri* tris;

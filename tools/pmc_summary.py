@@ -5,7 +5,7 @@ import glob
 import sys
 
 d = sys.argv[1]
-needle = sys.argv[2] if len(sys.argv) > 2 else "bounce_kernel"
+needle = sys.argv[2] if len(sys.argv) > 2 else "search_kernel"
 agg = collections.defaultdict(float)
 n = collections.defaultdict(int)
 for path in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
