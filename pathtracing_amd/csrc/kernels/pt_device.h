@@ -53,7 +53,9 @@ PT_HD Ray camera_get_ray(const DCamera& cam, uint32_t px, uint32_t py, Rng& rng)
     if (cam.bokeh_shape == 1u) { // circle
         float phi = rng.gen_range(0.0f, 2.0f * kPi);
         float r = sqrt_rn(rng.gen_range(0.0f, 1.0f));
-        sample = mk2(ptm::cos_f32(phi), ptm::sin_f32(phi)) * r;
+        float sphi, cphi;
+        ptm::sincos_f32(phi, &sphi, &cphi);
+        sample = mk2(cphi, sphi) * r;
     } else if (cam.bokeh_shape == 2u) { // square
         float sx = rng.gen_range(-0.5f, 0.5f);
         float sy = rng.gen_range(-0.5f, 0.5f);
@@ -113,7 +115,9 @@ PT_HD void triangle_finish(const LeafTri& tri, const ShadeTri& sh, const Ray& ra
 
 // ------------------------------------------------------------------ sphere / plane
 // sphere.rs:59-101
-PT_HD void sphere_trace(const DNode& n, uint32_t node_index, const Ray& ray, Hit* out) {
+// `want_uv` = false leaves uv at (0, 0): the caller knows nothing will read it
+// (the sphere's material has no texture), and atan2 + asin are the bulk of the cost.
+PT_HD void sphere_trace(const DNode& n, uint32_t node_index, const Ray& ray, Hit* out, bool want_uv = true) {
     out->hit = 0u;
     out->hit_inside = 0u;
     out->t = 0.0f;
@@ -137,8 +141,11 @@ PT_HD void sphere_trace(const DNode& n, uint32_t node_index, const Ray& ray, Hit
     V3 point = t * ray.direction + ray.source;
     float normal_facing_outside = inside ? -1.0f : 1.0f;
     V3 normal = (point - n.center) / (n.radius * normal_facing_outside);
-    float u = ptm::atan2_f32(normal.x, normal.z) / (2.0f * kPi) + 0.5f;
-    float v = ptm::asin_f32(normal.y) / kPi + 0.5f;
+    float u = 0.0f, v = 0.0f;
+    if (want_uv) {
+        u = ptm::atan2_f32(normal.x, normal.z) / (2.0f * kPi) + 0.5f;
+        v = ptm::asin_f32(normal.y) / kPi + 0.5f;
+    }
     out->hit = 1u;
     out->hit_inside = inside;
     out->t = t;
@@ -204,10 +211,14 @@ constexpr int kSpillStack = 48; // further entries in the lane's global spill co
 constexpr int kFrameDwords = 23;
 constexpr int kSpillDwords = kSpillStack + kMaxGraphDepth * kFrameDwords;
 
+// Both columns carry their address space in the pointer type, so pushes and pops
+// are LDS and global instructions (a generic pointer would make them flat ones).
+typedef __attribute__((address_space(3))) int32_t* LdsI32Ptr;
+typedef __attribute__((address_space(1))) uint32_t* GlobalU32Ptr;
 struct TravStack {
-    int32_t* lds; // this lane's column: lds[k * stride]
+    LdsI32Ptr lds; // this lane's column: lds[k * stride]
     int stride;
-    uint32_t* spill; // this lane's column: spill[k * spill_stride]
+    GlobalU32Ptr spill; // this lane's column: spill[k * spill_stride]
     uint32_t spill_stride;
     int sp;
     __device__ __forceinline__ void push(int32_t v) {
@@ -220,13 +231,13 @@ struct TravStack {
         sp--;
         return sp < kLdsStack ? lds[sp * stride] : (int32_t)spill[(size_t)(sp - kLdsStack) * spill_stride];
     }
-    __device__ __forceinline__ uint32_t* frame(int depth) const {
+    __device__ __forceinline__ GlobalU32Ptr frame(int depth) const {
         return spill + (size_t)(kSpillStack + depth * kFrameDwords) * spill_stride;
     }
 };
 
 __device__ __forceinline__ void spill_store_ray(const TravStack& st, int depth, const Ray& r) {
-    uint32_t* f = st.frame(depth);
+    GlobalU32Ptr f = st.frame(depth);
     const size_t s = st.spill_stride;
     f[0 * s] = __float_as_uint(r.source.x);
     f[1 * s] = __float_as_uint(r.source.y);
@@ -238,7 +249,7 @@ __device__ __forceinline__ void spill_store_ray(const TravStack& st, int depth, 
     f[7 * s] = __float_as_uint(r.max);
 }
 __device__ __forceinline__ Ray spill_load_ray(const TravStack& st, int depth) {
-    const uint32_t* f = st.frame(depth);
+    GlobalU32Ptr f = st.frame(depth);
     const size_t s = st.spill_stride;
     Ray r;
     r.source = mk3(__uint_as_float(f[0 * s]), __uint_as_float(f[1 * s]), __uint_as_float(f[2 * s]));
@@ -248,7 +259,7 @@ __device__ __forceinline__ Ray spill_load_ray(const TravStack& st, int depth) {
     return r;
 }
 __device__ __forceinline__ void spill_store_hit(const TravStack& st, int depth, const Hit& h) {
-    uint32_t* f = st.frame(depth) + (size_t)8 * st.spill_stride;
+    GlobalU32Ptr f = st.frame(depth) + (size_t)8 * st.spill_stride;
     const size_t s = st.spill_stride;
     f[0 * s] = __float_as_uint(h.t);
     f[1 * s] = h.hit | (h.hit_inside << 1);
@@ -265,7 +276,7 @@ __device__ __forceinline__ void spill_store_hit(const TravStack& st, int depth, 
     f[12 * s] = __float_as_uint(h.uv.y);
 }
 __device__ __forceinline__ Hit spill_load_hit(const TravStack& st, int depth) {
-    const uint32_t* f = st.frame(depth) + (size_t)8 * st.spill_stride;
+    GlobalU32Ptr f = st.frame(depth) + (size_t)8 * st.spill_stride;
     const size_t s = st.spill_stride;
     Hit h;
     h.t = __uint_as_float(f[0 * s]);
@@ -300,8 +311,25 @@ __device__ __forceinline__ bool box_test(const float* bmin, const float* bmax, V
     return lo <= hi;
 }
 
+// Scene arrays are reached through pointers stored in device memory, which the
+// compiler must take for generic addresses (flat loads); they always point into
+// global memory, so say so and get global loads.
+typedef float F4V __attribute__((ext_vector_type(4)));
+struct GlobalF4Ptr {
+    const __attribute__((address_space(1))) F4V* p;
+    __device__ __forceinline__ float4 operator[](int i) const {
+        F4V v = p[i];
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+};
+__device__ __forceinline__ GlobalF4Ptr global_f4(const void* p) {
+    GlobalF4Ptr g;
+    g.p = (const __attribute__((address_space(1))) F4V*)(unsigned long long)p;
+    return g;
+}
+
 __device__ __forceinline__ LeafTri load_tri(const LeafTri* p) {
-    const float4* q = reinterpret_cast<const float4*>(p);
+    GlobalF4Ptr q = global_f4(p);
     float4 a = q[0], b = q[1], c = q[2];
     LeafTri t;
     t.v0[0] = a.x; t.v0[1] = a.y; t.v0[2] = a.z; t.orig_index = __float_as_uint(a.w);
@@ -365,7 +393,7 @@ __device__ __forceinline__ bool trav_begin(const DMesh& mesh, const Ray& ray, Tr
 
 // One inner node: test both children, descend into the nearer, defer the other.
 __device__ __forceinline__ void trav_inner(TravState& ts, const Ray& ray, TravStack& st) {
-    const float4* q = reinterpret_cast<const float4*>(ts.nodes + ts.cur);
+    GlobalF4Ptr q = global_f4(ts.nodes + ts.cur);
     float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
     float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
     float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
@@ -524,7 +552,9 @@ __device__ __forceinline__ Ray transform_ray_c(const __attribute__((address_spac
     return o;
 }
 
-__device__ __forceinline__ int walk(const DScene& sc, WalkState& w, Hit& cur, bool resume, bool brute, TravStack& st) {
+// `all_uv` = false: texture coordinates are computed only where the node's material samples a texture.
+__device__ __forceinline__ int walk(const DScene& sc, WalkState& w, Hit& cur, bool resume, bool brute, TravStack& st,
+                                    bool all_uv = true) {
     const uint32_t n = sc.node_count;
     ConstNodePtr nodes = const_nodes(sc);
     // wave-uniform cursor (see above)
@@ -603,7 +633,9 @@ __device__ __forceinline__ int walk(const DScene& sc, WalkState& w, Hit& cur, bo
             nd.radius = nodes[i].radius;
             nd.radius_sqr = nodes[i].radius_sqr;
             nd.material_id = nodes[i].material_id;
-            sphere_trace(nd, i, w.ray, &cur);
+            typedef const __attribute__((address_space(4))) DMaterial* ConstMaterialPtr;
+            bool want_uv = all_uv || ((ConstMaterialPtr)(unsigned long long)sc.materials)[nd.material_id].color_is_texture != 0u;
+            sphere_trace(nd, i, w.ray, &cur, want_uv);
         } else {
             DNode nd;
             nd.point = cv3(nodes[i].point);
@@ -691,9 +723,11 @@ __device__ __forceinline__ V3 sample_color(const DMaterial& m, V2 uv) {
 __device__ __forceinline__ V3 random_on_unit_sphere(float rand_0, float rand_1) {
     float theta = rand_0 * kPi * 2.0f;
     float phi = ptm::acos_f32((2.0f * rand_1) - 1.0f);
-    float sp = ptm::sin_f32(phi), cp = ptm::cos_f32(phi);
-    float x = sp * ptm::cos_f32(theta);
-    float y = sp * ptm::sin_f32(theta);
+    float sp, cp, st, ct;
+    ptm::sincos_f32(phi, &sp, &cp);
+    ptm::sincos_f32(theta, &st, &ct);
+    float x = sp * ct;
+    float y = sp * st;
     return mk3(x, y, cp);
 }
 
@@ -776,7 +810,9 @@ __device__ __forceinline__ bool material_get_color(const DMaterial& m, V3 dir, c
         V3 k = cross(j, i);
         float r = sqrt_rn(r0);
         V3 rnd = j * (1.0f - r0 + kEpsilon);
-        output_dir = rnd + r * (i * ptm::cos_f32(theta) + k * ptm::sin_f32(theta));
+        float st, ct;
+        ptm::sincos_f32(theta, &st, &ct);
+        output_dir = rnd + r * (i * ct + k * st);
         selection_probability = dot(output_dir, normal);
         // brdf_diffuse, pbr.rs:64-73
         V3 h = normalized(output_dir + input_dir);

@@ -43,9 +43,9 @@ struct RenderParams {
 
 __device__ __forceinline__ TravStack make_stack(int32_t* lds_stack, uint32_t* spill, uint32_t spill_threads) {
     TravStack st;
-    st.lds = &lds_stack[threadIdx.x];
+    st.lds = (LdsI32Ptr)&lds_stack[threadIdx.x];
     st.stride = kBlock;
-    st.spill = spill + (blockIdx.x * kBlock + threadIdx.x);
+    st.spill = (GlobalU32Ptr)(spill + (blockIdx.x * kBlock + threadIdx.x));
     st.spill_stride = spill_threads;
     st.sp = 0;
     return st;
@@ -240,7 +240,7 @@ walk_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, uint32_t cap, uint
                 TravState ts;
                 walk_begin(w, ray);
                 bool resume = false;
-                while (walk(p.scene, w, cur, resume, brute, st) == kWalkMesh) {
+                while (walk(p.scene, w, cur, resume, brute, st, false) == kWalkMesh) {
                     const uint32_t m = const_nodes(p.scene)[__builtin_amdgcn_readfirstlane(w.i)].mesh_ordinal;
                     if (m < (uint32_t)kMaxDeferred) {
                         float4 res = b.res[m][base + item];

@@ -66,39 +66,42 @@ PT_HD float reduce_pio4(float ax, int* octant) {
     return ((ax - y * kDP1) - y * kDP2) - y * kDP3;
 }
 
-PT_HD float sin_f32(float x) {
-    float sign = 1.0f;
-    float ax = x;
-    if (x < 0.0f) {
-        sign = -1.0f;
-        ax = -x;
+// sin and cos of one argument from one reduction and one evaluation of the two
+// polynomials.  sin_f32 / cos_f32 are this function with one result dropped, so
+// calling it is interchangeable with calling them, bit for bit.
+PT_HD void sincos_f32(float x, float* s, float* c) {
+    bool neg = x < 0.0f;
+    float ax = neg ? -x : x;
+    if (!(ax <= 8192.0f)) { // out of the supported range (also NaN)
+        *s = 0.0f;
+        *c = 0.0f;
+        return;
     }
-    if (!(ax <= 8192.0f)) return 0.0f; // out of the supported range (also NaN)
     int j;
     float r = reduce_pio4(ax, &j);
-    if (j > 3) {
-        sign = -sign;
-        j -= 4;
-    }
+    bool half_turn = j > 3; // octants 4..7: both functions change sign
+    if (half_turn) j -= 4;
+    bool swap = j == 2;     // octants 2,3 (6,7): sin takes the cos polynomial and vice versa
     float z = r * r;
-    float y = (j == 2) ? cos_poly(z) : sin_poly(r, z);
-    return sign < 0.0f ? -y : y;
+    float sp = sin_poly(r, z), cp = cos_poly(z);
+    float ys = swap ? cp : sp;
+    float yc = swap ? sp : cp;
+    bool sin_neg = neg != half_turn;
+    bool cos_neg = half_turn != swap;
+    *s = sin_neg ? -ys : ys;
+    *c = cos_neg ? -yc : yc;
+}
+
+PT_HD float sin_f32(float x) {
+    float s, c;
+    sincos_f32(x, &s, &c);
+    return s;
 }
 
 PT_HD float cos_f32(float x) {
-    float sign = 1.0f;
-    float ax = abs_f32(x);
-    if (!(ax <= 8192.0f)) return 0.0f;
-    int j;
-    float r = reduce_pio4(ax, &j);
-    if (j > 3) {
-        sign = -sign;
-        j -= 4;
-    }
-    if (j > 1) sign = -sign;
-    float z = r * r;
-    float y = (j == 2) ? sin_poly(r, z) : cos_poly(z);
-    return sign < 0.0f ? -y : y;
+    float s, c;
+    sincos_f32(x, &s, &c);
+    return c;
 }
 
 PT_HD float asin_f32(float x) {
@@ -123,11 +126,25 @@ PT_HD float asin_f32(float x) {
     return x < 0.0f ? -p : p;
 }
 
+// acos(x) = pi - 2 asin(sqrt((1+x)/2)) below -0.5, 2 asin(sqrt((1-x)/2)) above 0.5,
+// pi/2 - asin(x) between; in all three the asin argument is at most 0.5 in
+// magnitude, so one evaluation of asin's small-argument form serves them all.
 PT_HD float acos_f32(float x) {
     if (!(abs_f32(x) <= 1.0f)) return __builtin_nanf("");
-    if (x < -0.5f) return kPi - 2.0f * asin_f32(sqrt_f32(0.5f * (1.0f + x)));
-    if (x > 0.5f) return 2.0f * asin_f32(sqrt_f32(0.5f * (1.0f - x)));
-    return kPiOver2 - asin_f32(x);
+    bool low = x < -0.5f, high = x > 0.5f;
+    float arg = x;
+    if (low || high) arg = sqrt_f32(0.5f * (1.0f + (low ? x : -x)));
+    float w = abs_f32(arg);
+    float r = arg;
+    if (!(w < 1.0e-4f)) {
+        float z = w * w;
+        float p = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z +
+                    7.4953002686e-2f) * z + 1.6666752422e-1f) * z * w + w;
+        r = arg < 0.0f ? -p : p;
+    }
+    if (low) return kPi - 2.0f * r;
+    if (high) return 2.0f * r;
+    return kPiOver2 - r;
 }
 
 PT_HD float atan_f32(float x) {
