@@ -751,60 +751,86 @@ __device__ __forceinline__ float powi5(float x) {
 
 // Material::get_color.  Returns true for GetColorResult::Color (value in *a),
 // false for NextRayColorMultiplierAndDirection (*a multiplier, *dir direction).
+//
+// Lanes of a wave meet different materials and branches, and the expensive part
+// of three of the branches is the same function of two random numbers (a point
+// on the unit sphere: base.rs:126-128 and pbr.rs:119 via lib.rs:272-289).  The
+// function therefore runs in three steps: draw and classify (cheap, divergent),
+// one shared evaluation of the sphere point for every lane that needs it, then
+// the branch-specific rest.  Each lane still executes exactly the arithmetic of
+// its own branch of the reference, in the reference's order of random draws.
 __device__ __forceinline__ bool material_get_color(const DMaterial& m, V3 dir, const Hit& tr, Rng& rng, V3* a,
                                                    V3* out_dir) {
+    enum { kReflect, kEmit, kRefract, kDiffuse, kPbrCosine, kPbrUniform };
+    int kind;
+    float u0 = 0.0f, u1 = 0.0f;
     if (m.type == 0u) { // base.rs:87-145
         float random_num = rng.gen_range(0.0f, 1.0f);
-        if (random_num < m.reflective) {
-            *a = splat3(1.0f);
-            *out_dir = reflect(dir, tr.normal);
-            return false;
-        } else if (random_num < m.reflective + m.emissive) {
-            *a = m.emission;
-            return true;
-        } else if (random_num < m.reflective + m.emissive + m.refractive) {
-            float cosv = dot(mk3(0, 0, 0) - dir, tr.normal);
-            float refraction = tr.hit_inside ? m.refraction : 1.0f / m.refraction;
-            float fresnel = fresnel_reflection(cosv, refraction);
-            float rnd = rng.gen_range(0.0f, 1.0f);
-            V3 new_dir;
-            if (rnd < fresnel) {
-                new_dir = reflect(dir, tr.normal);
-            } else {
-                // lib.rs:263-270
-                float d = dot(tr.normal, dir);
-                float k = 1.0f - refraction * refraction * (1.0f - d * d);
-                if (k < 0.0f) {
-                    V3 reflected = reflect(dir, tr.normal);
-                    new_dir = reflected * (tr.hit_inside ? -1.0f : 1.0f);
-                } else {
-                    new_dir = refraction * dir - tr.normal * (refraction * d + sqrt_rn(k));
-                }
-            }
-            *a = splat3(1.0f);
-            *out_dir = new_dir;
-            return false;
-        } else {
-            float r0 = rng.gen_range(0.0f, 1.0f);
-            float r1 = rng.gen_range(0.0f, 1.0f);
-            V3 new_direction = random_on_unit_sphere(r0, r1);
-            if (dot(new_direction, tr.normal) < 0.0f) new_direction = mk3(0, 0, 0) - new_direction;
-            *a = sample_color(m, tr.uv);
-            *out_dir = new_direction;
-            return false;
+        if (random_num < m.reflective) kind = kReflect;
+        else if (random_num < m.reflective + m.emissive) kind = kEmit;
+        else if (random_num < m.reflective + m.emissive + m.refractive) kind = kRefract;
+        else {
+            kind = kDiffuse;
+            u0 = rng.gen_range(0.0f, 1.0f);
+            u1 = rng.gen_range(0.0f, 1.0f);
         }
+    } else { // pbr.rs:105-110
+        u0 = rng.gen_range(0.0f, 1.0f);
+        u1 = rng.gen_range(0.0f, 1.0f);
+        kind = rng.gen_bool_half() ? kPbrCosine : kPbrUniform;
     }
-    // pbr.rs:105-136
+
+    V3 sphere_point = mk3(0, 0, 0);
+    if (kind == kDiffuse || kind == kPbrUniform) sphere_point = random_on_unit_sphere(u0, u1);
+
+    if (kind == kReflect) {
+        *a = splat3(1.0f);
+        *out_dir = reflect(dir, tr.normal);
+        return false;
+    }
+    if (kind == kEmit) {
+        *a = m.emission;
+        return true;
+    }
+    if (kind == kRefract) {
+        float cosv = dot(mk3(0, 0, 0) - dir, tr.normal);
+        float refraction = tr.hit_inside ? m.refraction : 1.0f / m.refraction;
+        float fresnel = fresnel_reflection(cosv, refraction);
+        float rnd = rng.gen_range(0.0f, 1.0f);
+        V3 new_dir;
+        if (rnd < fresnel) {
+            new_dir = reflect(dir, tr.normal);
+        } else {
+            // lib.rs:263-270
+            float d = dot(tr.normal, dir);
+            float k = 1.0f - refraction * refraction * (1.0f - d * d);
+            if (k < 0.0f) {
+                V3 reflected = reflect(dir, tr.normal);
+                new_dir = reflected * (tr.hit_inside ? -1.0f : 1.0f);
+            } else {
+                new_dir = refraction * dir - tr.normal * (refraction * d + sqrt_rn(k));
+            }
+        }
+        *a = splat3(1.0f);
+        *out_dir = new_dir;
+        return false;
+    }
+    if (kind == kDiffuse) {
+        V3 new_direction = sphere_point;
+        if (dot(new_direction, tr.normal) < 0.0f) new_direction = mk3(0, 0, 0) - new_direction;
+        *a = sample_color(m, tr.uv);
+        *out_dir = new_direction;
+        return false;
+    }
+    // pbr.rs:111-136
     V3 input_dir = dir * -1.0f;
-    float rand_0 = rng.gen_range(0.0f, 1.0f);
-    float rand_1 = rng.gen_range(0.0f, 1.0f);
     V3 normal = tr.normal;
-    V3 mulv, output_dir;
+    V3 output_dir;
     float selection_probability;
-    if (rng.gen_bool_half()) {
+    if (kind == kPbrCosine) {
         // lib.rs:196-212, :291-300
-        float r0 = ptm::cos_f32(kPi * 0.5f * (1.0f - rand_0));
-        float theta = rand_1 * kPi * 2.0f;
+        float r0 = ptm::cos_f32(kPi * 0.5f * (1.0f - u0));
+        float theta = u1 * kPi * 2.0f;
         V3 j = normal;
         V3 i = (abs_f(j.y) + abs_f(j.z) < kEpsilon) ? mk3(-j.y, j.x, 0.0f) : mk3(0.0f, j.z, -j.y);
         V3 k = cross(j, i);
@@ -814,21 +840,24 @@ __device__ __forceinline__ bool material_get_color(const DMaterial& m, V3 dir, c
         ptm::sincos_f32(theta, &st, &ct);
         output_dir = rnd + r * (i * ct + k * st);
         selection_probability = dot(output_dir, normal);
-        // brdf_diffuse, pbr.rs:64-73
-        V3 h = normalized(output_dir + input_dir);
-        V3 specular_k = m.f0 + (splat3(1.0f) - m.f0) * powi5(1.0f - dot(h, input_dir));
+    } else {
+        // lib.rs:282-289
+        V3 rnd = sphere_point;
+        output_dir = (dot(rnd, normal) < 0.0f) ? rnd * -1.0f : rnd;
+        selection_probability = 1.0f;
+    }
+    // fresnel, pbr.rs:60-62, evaluated by both brdf_diffuse (:64-73) and brdf_specular (:75-87)
+    V3 h = normalized(output_dir + input_dir);
+    V3 specular_k = m.f0 + (splat3(1.0f) - m.f0) * powi5(1.0f - dot(h, input_dir));
+    V3 mulv;
+    if (kind == kPbrCosine) {
         V3 diffuse_k = (splat3(1.0f) - specular_k) * (1.0f - m.metallic);
         V3 diffuse = kInvPi * m.albedo;
         mulv = diffuse_k * diffuse;
     } else {
-        // lib.rs:282-289
-        V3 rnd = random_on_unit_sphere(rand_0, rand_1);
-        output_dir = (dot(rnd, normal) < 0.0f) ? rnd * -1.0f : rnd;
-        selection_probability = 1.0f;
-        // brdf_specular, pbr.rs:75-87 with ndf :48-53, geometry :55-58, fresnel :60-62
+        // brdf_specular with ndf :48-53, geometry :55-58
         float ni = dot(normal, input_dir);
         float no = dot(normal, output_dir);
-        V3 h = normalized(output_dir + input_dir);
         float kk = ((1.0f + m.roughness) * (1.0f + m.roughness)) / 8.0f;
         float g_i = ni / (ni * (1.0f - kk) + kk);
         float g_o = no / (no * (1.0f - kk) + kk);
@@ -837,7 +866,6 @@ __device__ __forceinline__ bool material_get_color(const DMaterial& m, V3 dir, c
         float r4 = m.roughness_sqr * m.roughness_sqr;
         float denom_sqrt = nh * nh * (r4 - 1.0f) + 1.0f;
         float ndf = r4 / (denom_sqrt * denom_sqrt * kPi);
-        V3 specular_k = m.f0 + (splat3(1.0f) - m.f0) * powi5(1.0f - dot(h, input_dir));
         float specular = geometry * ndf / (4.0f * ni * no);
         mulv = specular_k * specular;
     }
