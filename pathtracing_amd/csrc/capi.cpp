@@ -120,10 +120,12 @@ struct PtScene {
         hip_check(hipMalloc(reinterpret_cast<void**>(&ws.job_counts), waves * sizeof(uint32_t)), "hipMalloc counts");
         hip_check(hipMalloc(reinterpret_cast<void**>(&ws.ray_total), 2 * sizeof(uint64_t)), "hipMalloc ray_total");
     }
-    void ensure_workspace(uint64_t paths) {
+    // Queues, results and contributions for batches of `samples` samples of nbx x nby pixel blocks.
+    void ensure_workspace(uint32_t nbx, uint32_t nby, uint32_t samples) {
         ensure_trace_state();
+        uint64_t paths = (uint64_t)nbx * nby * 64 * samples;
         uint32_t waves = ws.persistent_blocks * (ptk::kTraceBlock / 64);
-        uint64_t records = (uint64_t)ptk::queue_region_capacity(paths, waves) * waves;
+        uint64_t records = (uint64_t)ptk::queue_region_capacity(nbx, nby, samples, waves) * waves;
         if (records <= ws.capacity_paths && paths <= ws.contrib_paths) return;
         free_workspace();
         for (int q = 0; q < 2; q++)
@@ -360,7 +362,7 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
     if (band_block_rows > total_block_rows) band_block_rows = total_block_rows;
     uint64_t band_slots = (uint64_t)band_block_rows * slots_per_block_row;
     uint32_t samples_per_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / band_slots, task->iterations ? task->iterations : 1));
-    scene->ensure_workspace(band_slots * samples_per_batch);
+    scene->ensure_workspace(nbx, band_block_rows, samples_per_batch);
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (stats) {

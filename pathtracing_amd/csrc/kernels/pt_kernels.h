@@ -38,8 +38,8 @@ struct Workspace {
 };
 size_t spill_dwords_per_thread();
 uint32_t segment_blocks_per_cu(); // resident blocks per compute unit the trace kernels are built for
-// Records per wave region for a batch of `paths` path slots on a grid of `waves` waves.
-uint32_t queue_region_capacity(uint64_t paths, uint32_t waves);
+// Records per wave region for a batch of `samples` samples of nbx x nby pixel blocks on a grid of `waves` waves.
+uint32_t queue_region_capacity(uint32_t nbx, uint32_t nby, uint32_t samples, uint32_t waves);
 constexpr uint32_t kTraceBlock = 256;
 
 constexpr int kMaxDeferred = 4; // mesh nodes of a scene whose searches go through the search kernel

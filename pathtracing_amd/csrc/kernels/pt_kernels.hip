@@ -85,8 +85,22 @@ struct SegmentBuffers {
 // -------------------------------------------------------------- camera kernel
 // Camera::get_ray (camera.rs:51-83) for every path of the batch: path slot ->
 // (sample, pixel), the first draws of the path's random stream, the ray into the
-// wave's region of the first segment's queue.  64-slot chunks (8x8 pixels of one
-// sample) go round-robin over the regions.
+// wave's region of the first segment's queue.
+//
+// Which wave gets which 64-slot chunk (8x8 pixels of one sample) decides what the
+// chip's eight L2 caches see for the rest of the path, because survivors stay in
+// their wave's region.  Workgroups b and b + 8 share an XCD and its L2, so the
+// waves of one XCD take whole rows of 8x8 blocks (row y goes to XCD y mod 8), in
+// row order, all samples of a block next to each other: at any moment the waves
+// of an XCD work on one short strip of the image, whose rays walk the same part
+// of each BVH.
+constexpr uint32_t kWavesPerBlock = kBlock / 64;
+// 8 when block rows are dealt to XCDs, 1 (no distinction) for grids that do not split
+// evenly and for images too low to give every XCD a few rows.
+__host__ __device__ inline uint32_t camera_xcd_classes(uint32_t regions, uint32_t nby) {
+    return (regions % (8u * kWavesPerBlock) == 0u && nby >= 32u) ? 8u : 1u;
+}
+
 __global__ void __launch_bounds__(kBlock)
 camera_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions) {
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
@@ -94,19 +108,27 @@ camera_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions) 
     const uint32_t wave = tid >> 6;
     const uint32_t waves = (gridDim.x * kBlock) >> 6;
     const uint64_t total = (uint64_t)p.sample_count * p.geo.npp;
-    const uint32_t chunks_total = (uint32_t)((total + 63u) >> 6);
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const uint32_t xcds = camera_xcd_classes(regions, p.geo.nby);
+    const uint32_t regions_per_xcd = regions / xcds;
     for (uint32_t r = wave; r < regions; r += waves) {
         const size_t base = (size_t)r * cap;
         uint32_t out_pos = 0u;
-        for (uint32_t chunk = r; chunk < chunks_total; chunk += regions) {
-            uint64_t slot = (uint64_t)chunk * 64u + lane;
+        // region r belongs to workgroup r / 4, whose XCD class is (r / 4) mod 8
+        const uint32_t xcd = (r / kWavesPerBlock) % xcds;
+        const uint32_t index_in_xcd = (r / (kWavesPerBlock * xcds)) * kWavesPerBlock + (r % kWavesPerBlock);
+        const uint32_t rows = xcd < p.geo.nby ? (p.geo.nby - xcd + xcds - 1u) / xcds : 0u; // block rows of this XCD
+        const uint64_t work = (uint64_t)rows * p.geo.nbx * p.sample_count;                   // chunks of this XCD
+        for (uint64_t v = index_in_xcd; v < work; v += regions_per_xcd) {
+            const uint32_t s_local = (uint32_t)(v % p.sample_count);
+            const uint32_t k = (uint32_t)(v / p.sample_count);
+            const uint32_t bx = k % p.geo.nbx, by = (k / p.geo.nbx) * xcds + xcd;
+            const uint32_t q = (by * p.geo.nbx + bx) * 64u + lane;
+            const uint64_t slot = (uint64_t)s_local * p.geo.npp + q;
             bool have = false;
             Ray ray;
             uint32_t rng_counter = 0;
             if (slot < total) {
-                uint32_t s_local = (uint32_t)(slot / p.geo.npp);
-                uint32_t q = (uint32_t)(slot % p.geo.npp);
                 uint32_t x, y;
                 path_slot_to_pixel(p.geo, q, &x, &y, &have);
                 if (have) {
@@ -528,9 +550,12 @@ __global__ void __launch_bounds__(kBlock) shade_kernel(DScene scene, const PtVec
 // ------------------------------------------------------------------ launchers
 
 size_t spill_dwords_per_thread() { return (size_t)kSpillDwords; }
-uint32_t queue_region_capacity(uint64_t paths, uint32_t waves) {
-    uint64_t chunks = (paths + 63) / 64;
-    uint64_t per_wave = (chunks + waves - 1) / waves;
+uint32_t queue_region_capacity(uint32_t nbx, uint32_t nby, uint32_t samples, uint32_t waves) {
+    // the XCD with the most block rows sets the size (see camera_kernel)
+    uint32_t xcds = camera_xcd_classes(waves, nby);
+    uint64_t chunks = (uint64_t)((nby + xcds - 1) / xcds) * nbx * samples;
+    uint64_t waves_per_xcd = waves / xcds;
+    uint64_t per_wave = (chunks + waves_per_xcd - 1) / waves_per_xcd;
     return (uint32_t)(per_wave * 64);
 }
 static_assert(kTraceBlock == (uint32_t)kBlock, "block size mismatch");
@@ -554,7 +579,7 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
     if (total == 0 || trace_depth == 0) return hipSuccess;
     if (!ws.spill || ws.persistent_blocks == 0 || total > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const uint32_t regions = ws.persistent_blocks * (kBlock / 64);
-    const uint32_t cap = queue_region_capacity(total, regions);
+    const uint32_t cap = queue_region_capacity(geo.nbx, geo.nby, sample_count, regions);
     if ((uint64_t)cap * regions > ws.capacity_paths || total > ws.contrib_paths) return hipErrorInvalidValue;
     // mesh nodes searched ahead of the walk; the linear-scan mode searches nothing ahead
     const uint32_t searched = brute ? 0u : std::min<uint32_t>((uint32_t)targets.size(), (uint32_t)kMaxDeferred);
