@@ -130,3 +130,31 @@ def write_dragon_scene(out_dir: str, fixtures_dir: str, nu: int = DRAGON_NU, nv:
     with open(task, "w") as f:
         json.dump(dragon_render_task(), f, indent=1)
     return task
+
+
+def instanced_dragon_scene_json(count: int, seed: int = 0, half: float = 40.0, spacing: float = 26.0) -> dict:
+    """`count` transform -> kd_tree -> mesh instances of dragon.obj on a jittered grid
+    (rotation about y, uniform scale 1.0..1.3, seeded) inside a larger box: the
+    instanced workload, with the scene graph itself as the list of instances."""
+    import math
+    import random
+
+    rnd = random.Random(seed)
+    side = max(1, math.ceil(math.sqrt(count)))
+    children = [{"type": "sphere", "center": [0.0, half, half], "radius": 8.0, "material": "./materials/mat0.json"}]
+    for i in range(count):
+        gx, gz = i % side, i // side
+        x = (gx - (side - 1) / 2) * spacing + rnd.uniform(-2.0, 2.0)
+        z = (gz - (side - 1) / 2) * spacing + rnd.uniform(-2.0, 2.0)
+        a, sc = rnd.uniform(0.0, 2.0 * math.pi), rnd.uniform(1.0, 1.3)
+        c, s_ = math.cos(a) * sc, math.sin(a) * sc
+        matrix = [[c, 0.0, s_, x], [0.0, sc, 0.0, -2.0], [-s_, 0.0, c, z], [0.0, 0.0, 0.0, 1.0]]
+        mesh = {"type": "mesh", "path": "./dragon.obj", "material": "./materials/mat4.json" if i % 2 else "./materials/mat5.json"}
+        children.append({"type": "transform", "matrix": matrix,
+                         "child": {"type": "kd_tree", "path": "./dragon.tree", "child": mesh}})
+    children += [
+        _plane([0.0, -half, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, -1.0], [1.0, 0.0, 0.0], "./materials/mat2.json"),
+        _plane([0.0, half, 0.0], [0.0, -1.0, 0.0], [0.0, 0.0, -1.0], [1.0, 0.0, 0.0], "./materials/mat0.json"),
+        _plane([0.0, 0.0, -half], [0.0, 0.0, 1.0], [0.0, 1.0, 0.0], [1.0, 0.0, 0.0], "./materials/mat3.json"),
+    ]
+    return {"type": "node_collection", "children": children}

@@ -1,0 +1,126 @@
+"""The benchmark configurations at their full sizes, checked through properties
+that do not need a CPU render of the same size: splitting a frame by rows or by
+sample range and summing gives the frame, a render repeats bit for bit, frame
+means agree with a small oracle render of the same scene."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import pathtracing_amd as P
+from pathtracing_amd import distributed as D
+from pathtracing_amd import synth
+from tests import helpers as H
+from tests import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def test_textured_scene_1080p_16spp(oracle):
+    """scene0.json (two textures, PBR spheres), 1920x1080, 16 samples, depth 8."""
+    scene = P.Scene.load(H.SCENE_DATA, "./scene0.json")
+    gpu = P.HipRenderer.init(scene, 0)
+    task = H.load_task()
+    task.scene = "./scene0.json"
+    task.camera.resolution = [1920, 1080]
+    task.config = P.Config(trace_depth=8, iterations=16)
+    full = gpu.render(task, P.RenderOpts(seed=1))
+    assert gpu.last_stats.paths == 1920 * 1080 * 16
+    assert np.array_equal(H.bits(full), H.bits(gpu.render(task, P.RenderOpts(seed=1)))), "render does not repeat"
+    # three row bands, as three ranks would render them, reassemble the frame bit for bit
+    total = np.zeros_like(full)
+    for rank in range(3):
+        sub, opts = D.shard_opts(task, 3, rank, "rows", seed=1)
+        total += gpu.render(sub, opts)
+    assert np.array_equal(H.bits(total), H.bits(full))
+    # two sample ranges: equal up to the order of the f32 sums
+    halves = []
+    for rank in range(2):
+        sub, opts = D.shard_opts(task, 2, rank, "samples", seed=1)
+        halves.append(gpu.render(sub, opts).astype(np.float64))
+    assert np.allclose((halves[0] + halves[1]) / 2, full, rtol=2e-6, atol=1e-7)
+    # frame mean against the oracle (literal mode: libm, linear scan) at 1/64 of the pixels;
+    # both estimate the same integral, tolerance 2 %
+    small = H.load_task()
+    small.camera.resolution = [240, 135]
+    small.config = P.Config(trace_depth=8, iterations=16)
+    cpu = oracle.scene(scene.desc_pointer)
+    ref, _ = cpu.render(small, P.RenderOpts(seed=2), accel=ob.ACCEL_LINEAR, math=ob.MATH_LIBM)
+    cpu.close()
+    gpu.close()
+    assert abs(full.mean() - ref.mean()) <= 0.02 * ref.mean()
+
+
+@pytest.fixture(scope="module")
+def dragon_dir(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("dragon_cfg"))
+    return out, synth.write_dragon_scene(out, H.SCENE_DATA)
+
+
+def test_dragon_4k_256spp_in_eight_sample_ranges(dragon_dir):
+    """The dragon at 3840x2160, 256 samples split into 8 ranges of 32 as 8 GPUs would
+    take them (one GPU renders the ranges one after the other): their sum is the
+    256-sample frame up to the order of the f32 additions."""
+    out, task_path = dragon_dir
+    task = H.load_task(task_path)
+    task.camera.resolution = [3840, 2160]
+    task.config = P.Config(trace_depth=8, iterations=256)
+    gpu = P.HipRenderer.init(P.Scene.load(out, task.scene), 0)
+    full = gpu.render(task, P.RenderOpts(seed=0))
+    assert gpu.last_stats.paths == 3840 * 2160 * 256
+    rays_full = gpu.last_stats.rays
+    total = np.zeros(full.shape, dtype=np.float64)
+    rays = 0
+    for rank in range(8):
+        sub, opts = D.shard_opts(task, 8, rank, "samples", seed=0)
+        assert sub.config.iterations == 32 and opts.sample_offset == 32 * rank
+        total += gpu.render(sub, opts)
+        rays += gpu.last_stats.rays
+    gpu.close()
+    assert rays == rays_full  # the same paths were traced
+    # 256 f32 additions per pixel in two different orders: a few 1e-5 relative at worst
+    # (a path whose cosine-lobe sample hits the reference's sqrt(cos(pi/2)) < 0 case carries NaN
+    # to its pixel, here as there: a handful of pixels per 2e9 paths, the same ones both ways)
+    nan = np.isnan(full)
+    assert np.array_equal(nan, np.isnan(total)) and nan.mean() < 1e-4
+    err = np.abs(total / 8 - full)[~nan] / np.maximum(np.abs(full[~nan]), 1e-3)
+    # (multipliers of the PBR lobes may be large and of either sign, so single pixels cancel)
+    assert err.max() < 2e-3 and np.quantile(err, 0.999) < 2e-5, (err.max(), np.quantile(err, 0.999))
+
+
+def test_instanced_dragons_through_the_scene_graph(oracle, dragon_dir):
+    """Nine transformed instances of the 871k-triangle mesh (7.8 M triangles on
+    screen, one BVH in memory): closest hits against the oracle, which walks the same
+    scene graph.  More mesh nodes than the search kernel takes ahead of the walk, so
+    the walk kernel's own search is exercised on a large BVH as well."""
+    out, _ = dragon_dir
+    with open(os.path.join(out, "instanced.json"), "w") as f:
+        json.dump(synth.instanced_dragon_scene_json(9, seed=3), f)
+    scene = P.Scene.load(out, "./instanced.json")
+    gpu = P.HipRenderer.init(scene, 0)
+    cpu = oracle.scene(scene.desc_pointer)
+    rng = np.random.default_rng(17)
+    n = 200_000
+    src = np.stack([rng.uniform(-38, 38, n), rng.uniform(-30, 38, n), rng.uniform(-38, 38, n)], axis=1)
+    dst = np.stack([rng.uniform(-35, 35, n), rng.uniform(-14, 10, n), rng.uniform(-35, 35, n)], axis=1)
+    d = dst - src
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, :3], rays[:, 3:6], rays[:, 7] = src, d, H.F32_MAX
+    want = cpu.trace(rays, accel=ob.ACCEL_BVH, math=ob.MATH_PORTABLE)
+    H.assert_hits_identical(gpu.trace_closest(rays), want, "instanced dragons")
+    on_mesh = (want["hit"] == 1) & (want["tri_index"] != 0xFFFFFFFF)
+    assert on_mesh.mean() > 0.2 and np.unique(want["node_index"][on_mesh]).size == 9
+    # a small render through the wavefront pipeline, bit for bit
+    task = H.load_task()
+    task.camera.resolution = [96, 64]
+    task.camera.position = [0.0, 10.0, 110.0]
+    task.camera.focal_length = 110.0
+    task.config = P.Config(trace_depth=6, iterations=2)
+    got = gpu.render(task, P.RenderOpts(seed=4))
+    ref, st = cpu.render(task, P.RenderOpts(seed=4), accel=ob.ACCEL_BVH, math=ob.MATH_PORTABLE)
+    assert gpu.last_stats.rays == st.rays
+    assert np.array_equal(H.bits(got), H.bits(ref))
+    gpu.close()
+    cpu.close()
