@@ -99,6 +99,12 @@ struct PtScene {
                 (void)hipFree(ws.results[k]);
                 ws.results[k] = nullptr;
             }
+        for (int k = 0; k < 2; k++) {
+            if (ws.hits[k]) (void)hipFree(ws.hits[k]);
+            ws.hits[k] = nullptr;
+        }
+        if (ws.hit_uv_y) (void)hipFree(ws.hit_uv_y);
+        ws.hit_uv_y = nullptr;
         if (ws.contrib) (void)hipFree(ws.contrib);
         ws.contrib = nullptr;
         ws.capacity_paths = 0;
@@ -137,6 +143,9 @@ struct PtScene {
                 hip_check(hipMalloc(reinterpret_cast<void**>(&ws.jobs[k]), records * sizeof(float4)), "hipMalloc jobs");
         for (uint32_t k = 0; k < result_arrays; k++)
             hip_check(hipMalloc(reinterpret_cast<void**>(&ws.results[k]), records * sizeof(float4)), "hipMalloc results");
+        for (int k = 0; k < 2; k++)
+            hip_check(hipMalloc(reinterpret_cast<void**>(&ws.hits[k]), records * sizeof(float4)), "hipMalloc hits");
+        hip_check(hipMalloc(reinterpret_cast<void**>(&ws.hit_uv_y), records * sizeof(float)), "hipMalloc hits");
         hip_check(hipMalloc(reinterpret_cast<void**>(&ws.contrib), paths * 3 * sizeof(float)), "hipMalloc contrib");
         ws.capacity_paths = records;
         ws.contrib_paths = paths;

@@ -27,6 +27,9 @@ struct Workspace {
     float4* jobs[3] = {nullptr, nullptr, nullptr};
     uint32_t* job_counts = nullptr;
     float4* results[4] = {nullptr, nullptr, nullptr, nullptr};
+    // the segment's hit per ray, indexed like a queue: (point, material | inside << 31) (normal, uv.x), uv.y
+    float4* hits[2] = {nullptr, nullptr};
+    float* hit_uv_y = nullptr;
     float* contrib = nullptr;    // 3 floats per path of the batch: its final colour
     uint64_t capacity_paths = 0; // records each queue array holds
     uint64_t contrib_paths = 0;  // paths the contribution buffer holds

@@ -3,10 +3,11 @@
 // One batch = some consecutive samples of every pixel of a rectangle.  Per batch:
 //   camera_kernel        the batch's camera rays
 //   per path segment:    jobs_kernel + search_kernel for each mesh node of the
-//                        scene graph (closest triangle per ray), then walk_kernel:
-//                        scene-graph walk + material sampling; survivors go to the
-//                        wave's region of the other queue, finished paths store
-//                        their colour into the contribution buffer
+//                        scene graph (closest triangle per ray), walk_kernel
+//                        (scene-graph walk: the segment's hit), bounce_kernel
+//                        (material sampling; survivors go to the wave's region of
+//                        the other queue, finished paths store their colour into
+//                        the contribution buffer)
 //   accumulate_kernel    per pixel, adds the batch's contributions in sample order
 // (work_group.rs:26-69 is the per-pixel loop this replaces).
 #include <hip/hip_runtime.h>
@@ -80,6 +81,8 @@ struct SegmentBuffers {
     float4 *next_a, *next_b, *next_c;
     uint32_t* next_counts;
     float4* res[kMaxDeferred];
+    float4 *hit_a, *hit_b; // the segment's hits, written by walk_kernel for bounce_kernel
+    float* hit_c;
 };
 
 // -------------------------------------------------------------- camera kernel
@@ -206,26 +209,92 @@ jobs_kernel(DScene scene, MeshTarget target, const float4* __restrict__ ray_a, c
 }
 
 // ---------------------------------------------------------------- walk kernel
-// Everything of a path segment (work_group.rs:29-47) except the BVH searches,
-// which have run before it: scene-graph walk with the closest triangle of every
-// mesh node read from res[], material sampling, queueing of the next segment's
-// ray or the path's final colour.  Scenes with more than kMaxDeferred mesh nodes,
-// and the linear-scan mode, search the remaining meshes in place.
+// hierarchy.trace_ray of a path segment (work_group.rs:30) with the BVH searches
+// already done: the scene-graph walk, with the closest triangle of every mesh node
+// read from res[].  Writes the segment's hit, indexed like the ray:
+//   hit_a (point.xyz, material id | hit_inside << 31; 0xFFFFFFFF = nothing hit)
+//   hit_b (normal.xyz, uv.x)      hit_c uv.y
+// Scenes with more than kMaxDeferred mesh nodes, and the linear-scan mode, search
+// the remaining meshes in place.  The walk keeps two hit records and a ray per lane
+// alive (3 waves per SIMD); everything that can run at full occupancy is left to
+// bounce_kernel.
 #ifndef PT_WALK_OCCUPANCY
 #define PT_WALK_OCCUPANCY 3
 #endif
 __global__ void __launch_bounds__(kBlock, PT_WALK_OCCUPANCY)
-walk_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, uint32_t cap, uint32_t regions, float* contrib,
-            unsigned long long* ray_total, uint32_t* spill, uint32_t spill_threads) {
+walk_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions, unsigned long long* ray_total,
+            uint32_t* spill, uint32_t spill_threads) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
     const uint32_t waves = (gridDim.x * kBlock) >> 6;
-    const unsigned long long lane_lt = (1ull << lane) - 1ull;
     const bool brute = p.brute != 0u;
     TravStack st = make_stack(lds_stack, spill, spill_threads);
-    uint32_t traced = 0;
+    unsigned long long traced = 0;
+
+    for (uint32_t r = wave; r < regions; r += waves) {
+        const size_t base = (size_t)r * cap;
+        const uint32_t n_items = b.ray_counts[r];
+        traced += n_items;
+        for (uint32_t first = 0; first < n_items; first += 64u) {
+            const uint32_t item = first + lane;
+            if (item >= n_items) continue;
+            float4 ra = b.ray_a[base + item], rb = b.ray_b[base + item];
+            Ray ray;
+            ray.source = mk3(ra.x, ra.y, ra.z);
+            ray.min = ra.w;
+            ray.direction = mk3(rb.x, rb.y, rb.z);
+            ray.max = kF32Max;
+            Hit cur;
+            cur.hit = 0u;
+            cur.hit_inside = 0u;
+            cur.t = 0.0f;
+            cur.material_id = 0u;
+            cur.node_index = 0xFFFFFFFFu;
+            cur.tri_index = 0xFFFFFFFFu;
+            cur.point = mk3(0, 0, 0);
+            cur.normal = mk3(0, 0, 0);
+            cur.uv = mk2(0, 0);
+            WalkState w;
+            TravState ts;
+            walk_begin(w, ray);
+            bool resume = false;
+            while (walk(p.scene, w, cur, resume, brute, st, false) == kWalkMesh) {
+                const uint32_t m = const_nodes(p.scene)[__builtin_amdgcn_readfirstlane(w.i)].mesh_ordinal;
+                if (m < (uint32_t)kMaxDeferred) {
+                    float4 res = b.res[m][base + item];
+                    ts.tbest = res.x;
+                    ts.found = __float_as_uint(res.y);
+                    ts.best_slot = __float_as_uint(res.z);
+                    ts.best_orig = __float_as_uint(res.w);
+                } else {
+                    search_in_place(walk_mesh(p.scene, w), w.ray, st, ts);
+                }
+                walk_mesh_result(p.scene, w, ts, &cur);
+                resume = true;
+            }
+            uint32_t tag = cur.hit ? (cur.material_id | (cur.hit_inside << 31)) : 0xFFFFFFFFu;
+            b.hit_a[base + item] = make_float4(cur.point.x, cur.point.y, cur.point.z, __uint_as_float(tag));
+            b.hit_b[base + item] = make_float4(cur.normal.x, cur.normal.y, cur.normal.z, cur.uv.x);
+            b.hit_c[base + item] = cur.uv.y;
+        }
+    }
+    if (lane == 0u && traced) atomicAdd(ray_total, traced);
+}
+
+// -------------------------------------------------------------- bounce kernel
+// The rest of a path segment (work_group.rs:31-47): Material::get_color on the
+// hit the walk kernel found, texel fetch, then the next segment's ray into the
+// wave's region of the other queue, or the path's final colour into the
+// contribution buffer.
+__global__ void __launch_bounds__(kBlock)
+bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, uint32_t cap, uint32_t regions, float* contrib) {
+    const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+    const uint32_t waves = (gridDim.x * kBlock) >> 6;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
 
     for (uint32_t r = wave; r < regions; r += waves) {
         const size_t base = (size_t)r * cap;
@@ -233,54 +302,31 @@ walk_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, uint32_t cap, uint
         uint32_t out_pos = 0u;
         for (uint32_t first = 0; first < n_items; first += 64u) {
             const uint32_t item = first + lane;
-            const bool have = item < n_items;
             bool emit = false;
             Ray nray;
             V3 nmult = mk3(0, 0, 0);
             uint32_t path = 0, rng_counter = 0;
-            if (have) {
-                float4 ra = b.ray_a[base + item], rb = b.ray_b[base + item], rc = b.ray_c[base + item];
-                Ray ray;
-                ray.source = mk3(ra.x, ra.y, ra.z);
-                ray.min = ra.w;
-                ray.direction = mk3(rb.x, rb.y, rb.z);
-                ray.max = kF32Max;
+            if (item < n_items) {
+                float4 rb = b.ray_b[base + item], rc = b.ray_c[base + item];
+                float4 ha = b.hit_a[base + item];
                 path = __float_as_uint(rb.w);
-                V3 mult = mk3(rc.x, rc.y, rc.z);
                 rng_counter = __float_as_uint(rc.w);
-                Hit cur;
-                cur.hit = 0u;
-                cur.hit_inside = 0u;
-                cur.t = 0.0f;
-                cur.material_id = 0u;
-                cur.node_index = 0xFFFFFFFFu;
-                cur.tri_index = 0xFFFFFFFFu;
-                cur.point = mk3(0, 0, 0);
-                cur.normal = mk3(0, 0, 0);
-                cur.uv = mk2(0, 0);
-                WalkState w;
-                TravState ts;
-                walk_begin(w, ray);
-                bool resume = false;
-                while (walk(p.scene, w, cur, resume, brute, st, false) == kWalkMesh) {
-                    const uint32_t m = const_nodes(p.scene)[__builtin_amdgcn_readfirstlane(w.i)].mesh_ordinal;
-                    if (m < (uint32_t)kMaxDeferred) {
-                        float4 res = b.res[m][base + item];
-                        ts.tbest = res.x;
-                        ts.found = __float_as_uint(res.y);
-                        ts.best_slot = __float_as_uint(res.z);
-                        ts.best_orig = __float_as_uint(res.w);
-                    } else {
-                        search_in_place(walk_mesh(p.scene, w), w.ray, st, ts);
-                    }
-                    walk_mesh_result(p.scene, w, ts, &cur);
-                    resume = true;
-                }
-                // the segment's trace is complete: work_group.rs:31-47
-                traced++;
+                const uint32_t tag = __float_as_uint(ha.w);
                 V3 color = mk3(0, 0, 0);
                 bool finished = true;
-                if (cur.hit) {
+                if (tag != 0xFFFFFFFFu) {
+                    float4 hb = b.hit_b[base + item];
+                    Hit cur;
+                    cur.hit = 1u;
+                    cur.hit_inside = tag >> 31;
+                    cur.material_id = tag & 0x7FFFFFFFu;
+                    cur.t = 0.0f;
+                    cur.node_index = 0u;
+                    cur.tri_index = 0u;
+                    cur.point = mk3(ha.x, ha.y, ha.z);
+                    cur.normal = mk3(hb.x, hb.y, hb.z);
+                    cur.uv = mk2(hb.w, b.hit_c[base + item]);
+                    V3 mult = mk3(rc.x, rc.y, rc.z);
                     uint32_t s_local = path / p.geo.npp, q = path % p.geo.npp;
                     uint32_t x, y;
                     bool valid;
@@ -289,7 +335,7 @@ walk_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, uint32_t cap, uint
                     rng.key = stream_key(p.seed, stream_id(p.sample_first + s_local, (uint64_t)x + (uint64_t)y * p.cam.width));
                     rng.counter = rng_counter;
                     V3 av, dir;
-                    bool is_color = material_get_color(p.scene.materials[cur.material_id], w.ray.direction, cur, rng, &av, &dir);
+                    bool is_color = material_get_color(p.scene.materials[cur.material_id], mk3(rb.x, rb.y, rb.z), cur, rng, &av, &dir);
                     rng_counter = rng.counter;
                     if (is_color) {
                         color = mult * av;
@@ -322,13 +368,6 @@ walk_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, uint32_t cap, uint
         }
         if (lane == 0u) b.next_counts[r] = out_pos;
     }
-    unsigned long long traced_total = 0;
-    {
-        uint32_t v = traced;
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        traced_total = v;
-    }
-    if (lane == 0u && traced_total) atomicAdd(ray_total, traced_total);
 }
 
 // -------------------------------------------------------------- search kernel
@@ -577,7 +616,8 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
     p.brute = brute ? 1u : 0u;
     uint64_t total = (uint64_t)sample_count * geo.npp;
     if (total == 0 || trace_depth == 0) return hipSuccess;
-    if (!ws.spill || ws.persistent_blocks == 0 || total > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    if (!ws.spill || !ws.hits[0] || !ws.hits[1] || !ws.hit_uv_y || ws.persistent_blocks == 0 || total > 0xFFFFFFFFull)
+        return hipErrorInvalidValue;
     const uint32_t regions = ws.persistent_blocks * (kBlock / 64);
     const uint32_t cap = queue_region_capacity(geo.nbx, geo.nby, sample_count, regions);
     if ((uint64_t)cap * regions > ws.capacity_paths || total > ws.contrib_paths) return hipErrorInvalidValue;
@@ -600,6 +640,9 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
         b.next_c = ws.queue[out][2];
         b.next_counts = ws.wave_counts[out];
         for (int k = 0; k < kMaxDeferred; k++) b.res[k] = ws.results[k];
+        b.hit_a = ws.hits[0];
+        b.hit_b = ws.hits[1];
+        b.hit_c = ws.hit_uv_y;
         return b;
     };
     camera_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, buffers(0), cap, regions);
@@ -622,8 +665,8 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
                                                                       spill_threads);
             if (search_events && (e = hipEventRecord(e1, stream)) != hipSuccess) return e;
         }
-        walk_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, b, cap, regions, ws.contrib, rt, ws.spill,
-                                                                 spill_threads);
+        walk_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, b, cap, regions, rt, ws.spill, spill_threads);
+        bounce_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, b, cap, regions, ws.contrib);
     }
     accumulate_kernel<<<blocks_for(geo.npp), kBlock, 0, stream>>>(geo, cam.width, sample_count, ws.contrib, d_accum);
     return hipGetLastError();
