@@ -298,17 +298,20 @@ void build_mesh(PtScene& s, const PtMeshDesc& m, const PtTreeBlob* blob, ptk::DM
     }
     for (uint64_t k = 0; k < n; k++) leaf[k] = orig[bvh.order[k]];
 
-    out->nodes = s.upload(bvh.nodes);
+    pt::WideBvh wide = pt::widen_bvh(bvh);
+    if (wide.max_stack > ptk::traversal_stack_capacity())
+        throw Error(PT_ERR_UNSUPPORTED, "BVH needs a deeper traversal stack than the kernels keep");
+    out->nodes = s.upload(wide.nodes);
     out->tris = s.upload(leaf);
     out->tris_orig = s.upload(orig);
     out->shade = s.upload(shade);
     out->tri_count = (uint32_t)n;
-    out->node_count = (uint32_t)bvh.nodes.size();
-    out->root_ref = bvh.root_ref;
+    out->node_count = (uint32_t)wide.nodes.size();
+    out->root_ref = wide.root_ref;
     out->pad = 0;
     memcpy(out->bmin, bvh.bmin, sizeof(out->bmin));
     memcpy(out->bmax, bvh.bmax, sizeof(out->bmax));
-    s.bvh_bytes += bvh.nodes.size() * sizeof(ptk::BvhNode) + n * sizeof(ptk::LeafTri);
+    s.bvh_bytes += wide.nodes.size() * sizeof(ptk::WideNode) + n * sizeof(ptk::LeafTri);
 }
 
 ptk::DCamera make_camera(const PtCamera& c) {

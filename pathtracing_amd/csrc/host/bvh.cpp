@@ -318,6 +318,107 @@ BuiltBvh build_bvh(const float* positions, uint64_t triangle_count, uint32_t max
     return out;
 }
 
+WideBvh widen_bvh(const BuiltBvh& bvh) {
+    WideBvh out;
+    out.root_ref = bvh.root_ref;
+    if (bvh.root_ref < 0 || bvh.root_ref == ptk::kBvhSentinel) return out; // empty mesh or a single leaf
+    struct Child {
+        int32_t ref;
+        float mn[3], mx[3];
+    };
+    auto half_area = [](const Child& c) {
+        float dx = c.mx[0] - c.mn[0], dy = c.mx[1] - c.mn[1], dz = c.mx[2] - c.mn[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    auto children_of = [&](int32_t node, Child* two) {
+        const ptk::BvhNode& nd = bvh.nodes[node];
+        two[0].ref = nd.left;
+        two[1].ref = nd.right;
+        memcpy(two[0].mn, nd.lmin, 12);
+        memcpy(two[0].mx, nd.lmax, 12);
+        memcpy(two[1].mn, nd.rmin, 12);
+        memcpy(two[1].mx, nd.rmax, 12);
+    };
+    // returns {wide index, stack need below}
+    std::function<uint32_t(int32_t, int32_t*)> emit = [&](int32_t node, int32_t* index) -> uint32_t {
+        Child c[4];
+        int n = 2;
+        children_of(node, c);
+        while (n < 4) {
+            int pick = -1;
+            float best = -1.0f;
+            for (int i = 0; i < n; i++)
+                if (c[i].ref >= 0 && half_area(c[i]) > best) {
+                    best = half_area(c[i]);
+                    pick = i;
+                }
+            if (pick < 0) break;
+            Child two[2];
+            children_of(c[pick].ref, two);
+            c[pick] = two[0];
+            c[n++] = two[1];
+        }
+        int32_t me = (int32_t)out.nodes.size();
+        *index = me;
+        out.nodes.emplace_back();
+        ptk::WideNode w;
+        memset(&w, 0, sizeof(w));
+        double lo[3], hi[3];
+        for (int a = 0; a < 3; a++) {
+            lo[a] = c[0].mn[a];
+            hi[a] = c[0].mx[a];
+            for (int i = 1; i < n; i++) {
+                lo[a] = std::min(lo[a], (double)c[i].mn[a]);
+                hi[a] = std::max(hi[a], (double)c[i].mx[a]);
+            }
+        }
+        for (int a = 0; a < 3; a++) {
+            w.origin[a] = (float)lo[a]; // the smallest child minimum: a float already
+            double extent = hi[a] - lo[a];
+            int e = -126;
+            if (extent > 0.0) e = std::max(-126, (int)std::ceil(std::log2(extent / 255.0)) - 1);
+            for (;; e++) { // smallest step whose 255 cells cover the extent
+                double step = std::ldexp(1.0, e);
+                if (255.0 * step >= extent) break;
+            }
+            if (e > 127) throw Error(PT_ERR_UNSUPPORTED, "mesh extent too large for the node encoding");
+            double step = std::ldexp(1.0, e);
+            w.exponents |= (uint32_t)(e + 127) << (8 * a);
+            for (int i = 0; i < n; i++) {
+                double ql = std::floor(((double)c[i].mn[a] - lo[a]) / step);
+                double qh = std::ceil(((double)c[i].mx[a] - lo[a]) / step);
+                if (ql < 0.0) ql = 0.0;
+                if (qh > 255.0 || ql > 255.0) throw Error(PT_ERR_UNSUPPORTED, "node quantisation out of range");
+                // the decoded interval must contain the child's
+                if (lo[a] + ql * step > (double)c[i].mn[a] || lo[a] + qh * step < (double)c[i].mx[a])
+                    throw Error(PT_ERR_UNSUPPORTED, "node quantisation is not conservative");
+                w.qlo[a] |= (uint32_t)ql << (8 * i);
+                w.qhi[a] |= (uint32_t)qh << (8 * i);
+            }
+        }
+        uint32_t need_below = 0;
+        for (int i = 0; i < 4; i++) {
+            if (i >= n) {
+                w.child[i] = ptk::kBvhSentinel;
+                continue;
+            }
+            if (c[i].ref >= 0) {
+                int32_t idx;
+                need_below = std::max(need_below, emit(c[i].ref, &idx));
+                w.child[i] = idx;
+            } else {
+                w.child[i] = c[i].ref;
+            }
+        }
+        out.nodes[me] = w;
+        return (uint32_t)(n - 1) + need_below;
+    };
+    int32_t root;
+    out.max_stack = emit(bvh.root_ref, &root);
+    out.root_ref = root;
+    return out;
+}
+
 std::vector<uint8_t> serialize_tree(const BuiltBvh& bvh, const float* positions, uint64_t triangle_count) {
     TreeHeader h;
     memset(&h, 0, sizeof(h));

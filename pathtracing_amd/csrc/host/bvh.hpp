@@ -32,6 +32,15 @@ void padded_triangle_bounds(const float* p9, float reach, float* bmin, float* bm
 // Largest distance between a ray origin and the mesh that the padding budgets for.
 float padding_reach(const float* mesh_bmin, const float* mesh_bmax);
 
+// The device form of a tree (ptk::WideNode): every node takes its grandchildren
+// as children where that gives at most four, child boxes are quantised outwards.
+struct WideBvh {
+    std::vector<ptk::WideNode> nodes;
+    int32_t root_ref = ptk::kBvhSentinel; // node 0, or the leaf of a tiny mesh
+    uint32_t max_stack = 0;               // most entries a depth-first search can have pending
+};
+WideBvh widen_bvh(const BuiltBvh& bvh);
+
 std::vector<uint8_t> serialize_tree(const BuiltBvh& bvh, const float* positions, uint64_t triangle_count);
 // Returns false (and leaves `out` untouched) when the blob is empty, malformed,
 // built for other geometry, or not conservative for this mesh.

@@ -201,7 +201,7 @@ PT_HD Ray apply_transform(const Ray& r, const M4& inv, const M3& inv_normal) {
 // triangle inside it can report a hit at t <= the best so far.
 
 constexpr int kLdsStack = 16;   // traversal-stack entries per lane kept in LDS
-constexpr int kSpillStack = 48; // further entries in the lane's global spill column
+constexpr int kSpillStack = 112; // further entries in the lane's global spill column
 
 // Per-lane spill column in global memory (the kernels run a fixed, persistent
 // grid, so the area is sized once).  Dword k of lane `tid` lives at
@@ -348,7 +348,7 @@ __device__ __forceinline__ bool all_finite(V3 v) {
 // triangle index among equal t.  It is cut into steps so that a wave can stop,
 // hand finished lanes new rays and go on (see search_kernel).
 struct TravState {
-    const BvhNode* nodes;
+    const WideNode* nodes;
     const LeafTri* tris;
     V3 inv;
     float ray_limit; // ray.max, or +inf when it is NaN (a NaN max never rejects, triangle/mod.rs:155)
@@ -391,28 +391,97 @@ __device__ __forceinline__ bool trav_begin(const DMesh& mesh, const Ray& ray, Tr
     return true;
 }
 
-// One inner node: test both children, descend into the nearer, defer the other.
+// Byte `c` of a packed dword as a float (one v_cvt_f32_ubyteN).
+template <int C> __device__ __forceinline__ float byte_to_float(uint32_t packed) {
+    return (float)((packed >> (8 * C)) & 0xFFu);
+}
+
+// Entry distance of child C of a node into `*t`, or +inf when the ray misses the
+// child's box within [0, limit] (or the slot is empty).  near_q / far_q hold the
+// quantised plane coordinates the ray meets first / last on each axis; a = grid
+// step * 1/direction, bn / bf = (grid origin - ray origin) * 1/direction moved
+// down / up by the rounding slack (see trav_inner).  A NaN term (0 * inf: a ray
+// lying in a plane of the grid) is dropped by max3 / min3, which only makes the
+// test more permissive.
+template <int C>
+__device__ __forceinline__ float child_entry(const uint32_t* near_q, const uint32_t* far_q, V3 a, V3 bn, V3 bf,
+                                             float limit, int32_t ref) {
+    float nx = __builtin_fmaf(byte_to_float<C>(near_q[0]), a.x, bn.x), fx = __builtin_fmaf(byte_to_float<C>(far_q[0]), a.x, bf.x);
+    float ny = __builtin_fmaf(byte_to_float<C>(near_q[1]), a.y, bn.y), fy = __builtin_fmaf(byte_to_float<C>(far_q[1]), a.y, bf.y);
+    float nz = __builtin_fmaf(byte_to_float<C>(near_q[2]), a.z, bn.z), fz = __builtin_fmaf(byte_to_float<C>(far_q[2]), a.z, bf.z);
+    float lo = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
+    float hi = fminf(fminf(fx, fy), fminf(fz, limit));
+    return (lo <= hi && ref != kBvhSentinel) ? lo : f32_inf();
+}
+
+// Orders two (distance, reference) pairs by distance.
+__device__ __forceinline__ void order_pair(float& ta, int32_t& ra, float& tb, int32_t& rb) {
+    bool swap = tb < ta;
+    float t0 = swap ? tb : ta, t1 = swap ? ta : tb;
+    int32_t r0 = swap ? rb : ra, r1 = swap ? ra : rb;
+    ta = t0;
+    tb = t1;
+    ra = r0;
+    rb = r1;
+}
+
+// One inner node: test its (up to four) children, descend into the nearest, defer
+// the others nearest on top.
+//
+// The slab distances are evaluated on the node's grid: plane coordinate q (0..255)
+// of axis k lies at t = q * A + B with A = step_k / d_k, B = (origin_k - o_k) / d_k.
+// In f32 that is fl(q * A' + B') with A' = fl(step * inv) (exact: step is a power
+// of two), B' = fl(fl(origin - o) * inv), inv = fl(1 / d): against the exact value
+// the result is off by at most eps * (2 * 255 |A| + 4 |B|), eps = 2^-24.  Entry
+// distances are lowered and exit distances raised by twice that, so a box is
+// skipped only when the ray misses it outright; the triangle boxes below carry the
+// padding that makes "misses the box" imply "rejected by the f32 triangle test".
+// (Fused multiply-adds are used here on purpose: nothing of a hit record depends on
+// these values, only which boxes are opened.)
 __device__ __forceinline__ void trav_inner(TravState& ts, const Ray& ray, TravStack& st) {
     GlobalF4Ptr q = global_f4(ts.nodes + ts.cur);
     float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
-    float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
-    float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
-    int32_t left = __float_as_int(n3.x), right = __float_as_int(n3.y);
-    float limit = fminf(ts.tbest, ts.ray_limit);
-    float tl, tr;
-    bool hl = box_test(lmin, lmax, ray.source, ts.inv, limit, &tl);
-    bool hr = box_test(rmin, rmax, ray.source, ts.inv, limit, &tr);
-    if (hl && hr) {
-        bool left_first = tl <= tr;
-        st.push(left_first ? right : left);
-        ts.cur = left_first ? left : right;
-    } else if (hl) {
-        ts.cur = left;
-    } else if (hr) {
-        ts.cur = right;
-    } else {
-        ts.cur = st.pop();
+    const uint32_t exps = __float_as_uint(n0.w);
+    V3 step = mk3(__uint_as_float((exps & 0xFFu) << 23), __uint_as_float(((exps >> 8) & 0xFFu) << 23),
+                  __uint_as_float(((exps >> 16) & 0xFFu) << 23));
+    V3 a = mk3(step.x * ts.inv.x, step.y * ts.inv.y, step.z * ts.inv.z);
+    V3 b = mk3((n0.x - ray.source.x) * ts.inv.x, (n0.y - ray.source.y) * ts.inv.y, (n0.z - ray.source.z) * ts.inv.z);
+    const float k = 1.1920929e-7f; // 2 eps
+    V3 slack = mk3(__builtin_fmaf(abs_f(a.x), 512.0f * k, abs_f(b.x) * (4.0f * k)),
+                   __builtin_fmaf(abs_f(a.y), 512.0f * k, abs_f(b.y) * (4.0f * k)),
+                   __builtin_fmaf(abs_f(a.z), 512.0f * k, abs_f(b.z) * (4.0f * k)));
+    V3 bn = mk3(b.x - slack.x, b.y - slack.y, b.z - slack.z);
+    V3 bf = mk3(b.x + slack.x, b.y + slack.y, b.z + slack.z);
+    const uint32_t qlo[3] = {__float_as_uint(n1.x), __float_as_uint(n1.y), __float_as_uint(n1.z)};
+    const uint32_t qhi[3] = {__float_as_uint(n1.w), __float_as_uint(n2.x), __float_as_uint(n2.y)};
+    // a ray running towards smaller coordinates meets the high plane first
+    const bool back[3] = {ts.inv.x < 0.0f, ts.inv.y < 0.0f, ts.inv.z < 0.0f};
+    uint32_t near_q[3], far_q[3];
+    for (int k3 = 0; k3 < 3; k3++) {
+        near_q[k3] = back[k3] ? qhi[k3] : qlo[k3];
+        far_q[k3] = back[k3] ? qlo[k3] : qhi[k3];
     }
+    const float limit = fminf(ts.tbest, ts.ray_limit);
+    int32_t r0 = __float_as_int(n3.x), r1 = __float_as_int(n3.y), r2 = __float_as_int(n3.z), r3 = __float_as_int(n3.w);
+    float t0 = child_entry<0>(near_q, far_q, a, bn, bf, limit, r0);
+    float t1 = child_entry<1>(near_q, far_q, a, bn, bf, limit, r1);
+    float t2 = child_entry<2>(near_q, far_q, a, bn, bf, limit, r2);
+    float t3 = child_entry<3>(near_q, far_q, a, bn, bf, limit, r3);
+    // sort the four by entry distance (misses, at +inf, end up last)
+    order_pair(t0, r0, t1, r1);
+    order_pair(t2, r2, t3, r3);
+    order_pair(t0, r0, t2, r2);
+    order_pair(t1, r1, t3, r3);
+    order_pair(t1, r1, t2, r2);
+    const float inf = f32_inf();
+    if (t0 == inf) {
+        ts.cur = st.pop();
+        return;
+    }
+    if (t3 != inf) st.push(r3);
+    if (t2 != inf) st.push(r2);
+    if (t1 != inf) st.push(r1);
+    ts.cur = r0;
 }
 
 // One leaf: the reference's triangle test on each of its triangles.
@@ -660,11 +729,20 @@ __device__ __forceinline__ const DMesh& walk_mesh(const DScene& sc, const WalkSt
 }
 
 // A whole search, begun and run to its end by this lane.
+// (A search of a valid tree opens every node at most once; the step budget only
+// makes sure that a lane leaves these loops whatever the node array holds.)
 __device__ __forceinline__ void search_in_place(const DMesh& mesh, const Ray& ray, TravStack& st, TravState& ts) {
     if (!trav_begin(mesh, ray, st, ts)) return;
-    while (!trav_done(ts)) {
-        while (trav_is_inner(ts)) trav_inner(ts, ray, st);
-        if (!trav_done(ts)) trav_leaf(ts, ray, st);
+    uint32_t budget = 8u * mesh.node_count + 64u;
+    while (!trav_done(ts) && budget != 0u) {
+        while (trav_is_inner(ts) && budget != 0u) {
+            trav_inner(ts, ray, st);
+            budget--;
+        }
+        if (!trav_done(ts) && !trav_is_inner(ts)) {
+            trav_leaf(ts, ray, st);
+            budget--;
+        }
     }
 }
 

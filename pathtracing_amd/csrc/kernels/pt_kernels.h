@@ -40,6 +40,7 @@ struct Workspace {
     uint32_t persistent_blocks = 0;
 };
 size_t spill_dwords_per_thread();
+uint32_t traversal_stack_capacity(); // pending entries a lane's BVH search can hold
 uint32_t segment_blocks_per_cu(); // resident blocks per compute unit the trace kernels are built for
 // Records per wave region for a batch of `samples` samples of nbx x nby pixel blocks on a grid of `waves` waves.
 uint32_t queue_region_capacity(uint32_t nbx, uint32_t nby, uint32_t samples, uint32_t waves);

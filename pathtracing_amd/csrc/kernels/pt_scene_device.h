@@ -1,5 +1,7 @@
 // Device-resident scene layout (plain structs, uploaded once per scene).
 #pragma once
+#include <cstddef>
+
 #include "pt_vec.h"
 
 namespace ptk {
@@ -16,7 +18,26 @@ struct alignas(64) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 
-constexpr int32_t kBvhSentinel = 0x7FFFFFFF; // "stack empty"
+constexpr int32_t kBvhSentinel = 0x7FFFFFFF; // "stack empty" / "no child"
+
+// What the GPU searches: the same tree with every other level removed (up to four
+// children per node) and the children's boxes quantised to 8 bits per coordinate
+// on a grid local to the node, so that a node is one 64-byte fetch and a search
+// makes half as many dependent fetches.  Child c's box is, per axis a,
+//   [origin[a] + lo(a, c) * 2^e(a), origin[a] + hi(a, c) * 2^e(a)]
+// with lo rounded down and hi rounded up (the box only grows).  Children are
+// referenced like BvhNode's; unused slots hold kBvhSentinel.
+struct alignas(64) WideNode {
+    float origin[3];
+    uint32_t exponents; // byte a = biased f32 exponent of axis a's grid step, >= 1
+    uint32_t qlo[3];    // byte c of qlo[a] = lo(a, c)
+    uint32_t qhi[3];
+    uint32_t pad[2];
+    int32_t child[4];   // the last 16-byte row
+};
+static_assert(sizeof(WideNode) == 64 && offsetof(WideNode, child) == 48 && offsetof(WideNode, qlo) == 16 &&
+                  offsetof(WideNode, qhi) == 28,
+              "WideNode rows are read as four float4");
 constexpr int kLeafMaxTris = 8;
 constexpr int kBvhMaxDepth = 60; // builder guarantee; traversal stack holds 64
 
@@ -45,7 +66,7 @@ struct alignas(16) ShadeTri {
 static_assert(sizeof(ShadeTri) == 80, "ShadeTri must be 80 bytes");
 
 struct DMesh {
-    const BvhNode* nodes;   // node 0 is the root (absent when root_ref is a leaf)
+    const WideNode* nodes;  // node 0 is the root (absent when root_ref is a leaf)
     const LeafTri* tris;    // leaf order
     const LeafTri* tris_orig; // original order (brute-force scan)
     const ShadeTri* shade;  // original order
