@@ -373,6 +373,19 @@ __device__ __forceinline__ bool trav_reaches(const DMesh& mesh, const Ray& ray) 
     return mesh.root_ref != kBvhSentinel;
 }
 
+// 1 / direction for the box tests of a search, kept finite: on the node grids the
+// slab distances are sums of products with it (trav_inner), and an infinite factor
+// would turn them into NaNs, i.e. into "this axis does not constrain the ray" -- a
+// ray running exactly along a coordinate plane (a handful per million: mirror
+// bounces off axis-aligned walls, sample directions that are exactly 0) would then
+// open every box in a whole slab of the tree.  With +-1e28 in place of +-inf such a
+// ray is off by at least 1e8 on that axis unless it starts within 1e-20 of the
+// slab, which is as good as the exact answer and errs on the side of opening.
+__device__ __forceinline__ V3 search_inverse_direction(V3 d) {
+    const float big = 1.0e28f;
+    return mk3(clamp_f(1.0f / d.x, -big, big), clamp_f(1.0f / d.y, -big, big), clamp_f(1.0f / d.z, -big, big));
+}
+
 // Starts a search.  False: the ray cannot hit the mesh at all; `ts` then
 // describes a finished search without a hit.
 __device__ __forceinline__ bool trav_begin(const DMesh& mesh, const Ray& ray, TravStack& st, TravState& ts) {
@@ -385,7 +398,7 @@ __device__ __forceinline__ bool trav_begin(const DMesh& mesh, const Ray& ray, Tr
     ts.found = 0u;
     st.sp = 0;
     if (!trav_reaches(mesh, ray)) return false;
-    ts.inv = mk3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
+    ts.inv = search_inverse_direction(ray.direction);
     ts.ray_limit = (ray.max == ray.max) ? ray.max : f32_inf();
     ts.cur = mesh.root_ref;
     return true;

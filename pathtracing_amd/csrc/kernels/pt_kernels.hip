@@ -426,7 +426,7 @@ search_kernel(const DMesh* __restrict__ meshes, const float4* __restrict__ job_a
                 res_out = res + ((size_t)region * cap + v);
                 const DMesh& mesh = meshes[mesh_id];
                 // the jobs kernel has already checked the ray against the mesh bounds
-                ts.inv = mk3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
+                ts.inv = search_inverse_direction(ray.direction);
                 ts.ray_limit = (ray.max == ray.max) ? ray.max : f32_inf();
                 ts.nodes = mesh.nodes;
                 ts.tris = mesh.tris;
