@@ -89,3 +89,33 @@ def test_dragon_render_bit_exact(dragon):
     assert gpu.last_stats.rays == st.rays
     assert np.array_equal(H.bits(got), H.bits(want))
     assert got.mean() > 0.01
+
+
+def test_dragon_rays_along_coordinate_planes(dragon):
+    """Directions with components that are exactly zero (mirror bounces off the box
+    walls produce them): 1/direction is infinite on those axes, which the search's
+    box tests on the node grids have to survive without opening the whole tree and
+    without losing a hit."""
+    task, gpu, cpu = dragon
+    rng = np.random.default_rng(23)
+    n = 30_000
+    src = rng.uniform(-14, 14, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    kind = rng.integers(0, 6, n)
+    for axis in range(3):
+        d[kind == axis, axis] = 0.0  # lies in a coordinate plane
+        only = kind == 3 + axis  # runs along an axis
+        d[only] = 0.0
+        d[only, axis] = rng.choice([-1.0, 1.0], size=int(only.sum()))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # aim the origins so that most rays cross the mesh: shift them onto lines through points near the knot
+    verts, _ = synth.knot_mesh()
+    through = verts[rng.integers(0, verts.shape[0], n)] + np.array([0, -2, 0], dtype=np.float32)
+    src = (through - d * rng.uniform(5, 25, size=(n, 1))).astype(np.float32)
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, :3], rays[:, 3:6], rays[:, 7] = src, d.astype(np.float32), H.F32_MAX
+    assert (rays[:, 3:6] == 0).any(axis=1).all()
+    got = gpu.trace_closest(rays)
+    H.assert_hits_identical(got, gpu.trace_closest(rays, brute_force=True), "axis-parallel rays: BVH vs scan")
+    H.assert_hits_identical(got, cpu.trace(rays, accel=ob.ACCEL_BVH, math=ob.MATH_PORTABLE), "axis-parallel rays vs oracle")
+    assert ((got["hit"] == 1) & (got["tri_index"] != 0xFFFFFFFF)).mean() > 0.5
