@@ -383,7 +383,7 @@ WideBvh widen_bvh(const BuiltBvh& bvh) {
             }
             if (e > 127) throw Error(PT_ERR_UNSUPPORTED, "mesh extent too large for the node encoding");
             double step = std::ldexp(1.0, e);
-            w.exponents |= (uint32_t)(e + 127) << (8 * a);
+            (a == 0 ? w.step_x : w.step_yz[a - 1]) = (float)step;
             for (int i = 0; i < n; i++) {
                 double ql = std::floor(((double)c[i].mn[a] - lo[a]) / step);
                 double qh = std::ceil(((double)c[i].mx[a] - lo[a]) / step);
@@ -405,6 +405,7 @@ WideBvh widen_bvh(const BuiltBvh& bvh) {
             if (c[i].ref >= 0) {
                 int32_t idx;
                 need_below = std::max(need_below, emit(c[i].ref, &idx));
+                if (idx <= me) throw Error(PT_ERR_UNSUPPORTED, "wide node order"); // pre-order: cannot happen
                 w.child[i] = idx;
             } else {
                 w.child[i] = c[i].ref;

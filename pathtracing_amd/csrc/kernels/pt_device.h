@@ -454,9 +454,7 @@ __device__ __forceinline__ void order_pair(float& ta, int32_t& ra, float& tb, in
 __device__ __forceinline__ void trav_inner(TravState& ts, const Ray& ray, TravStack& st) {
     GlobalF4Ptr q = global_f4(ts.nodes + ts.cur);
     float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
-    const uint32_t exps = __float_as_uint(n0.w);
-    V3 step = mk3(__uint_as_float((exps & 0xFFu) << 23), __uint_as_float(((exps >> 8) & 0xFFu) << 23),
-                  __uint_as_float(((exps >> 16) & 0xFFu) << 23));
+    V3 step = mk3(n0.w, n2.z, n2.w);
     V3 a = mk3(step.x * ts.inv.x, step.y * ts.inv.y, step.z * ts.inv.z);
     V3 b = mk3((n0.x - ray.source.x) * ts.inv.x, (n0.y - ray.source.y) * ts.inv.y, (n0.z - ray.source.z) * ts.inv.z);
     const float k = 1.1920929e-7f; // 2 eps

@@ -398,10 +398,9 @@ search_kernel(const DMesh* __restrict__ meshes, const float4* __restrict__ job_a
     float4* res_out = nullptr;
     bool busy = false;
 
-    // (every pass of the loops below retires at least one step of some lane's search,
-    // and a search of a valid tree is finite; the pass count is capped all the same so
-    // that the grid drains whatever the node arrays hold)
-    uint32_t passes_left = 1u << 28;
+    // Every pass of the loops below retires at least one step of some lane's search, and
+    // a search ends: inner children have larger indices than their parents (WideNode),
+    // so the nodes a lane opens cannot repeat.
     for (;;) {
         // ---- hand jobs to idle lanes
         unsigned long long idle_mask = __ballot(!busy);
@@ -464,13 +463,11 @@ search_kernel(const DMesh* __restrict__ meshes, const float4* __restrict__ job_a
                     if (n_leaf != 0u) break;
                 }
                 if (at_inner) trav_inner(ts, ray, st);
-                if (--passes_left == 0u) return;
             }
             if (busy && !trav_done(ts) && !trav_is_inner(ts)) trav_leaf(ts, ray, st);
 #endif
             uint32_t n_unfinished = (uint32_t)__popcll(__ballot(busy && !trav_done(ts)));
             if (n_unfinished == 0u || (more && n_unfinished + kRefill <= n_busy)) break;
-            if (--passes_left == 0u) return;
         }
         if (busy && trav_done(ts)) {
             *res_out = make_float4(ts.tbest, __uint_as_float(ts.found), __uint_as_float(ts.best_slot),

@@ -24,19 +24,22 @@ constexpr int32_t kBvhSentinel = 0x7FFFFFFF; // "stack empty" / "no child"
 // children per node) and the children's boxes quantised to 8 bits per coordinate
 // on a grid local to the node, so that a node is one 64-byte fetch and a search
 // makes half as many dependent fetches.  Child c's box is, per axis a,
-//   [origin[a] + lo(a, c) * 2^e(a), origin[a] + hi(a, c) * 2^e(a)]
-// with lo rounded down and hi rounded up (the box only grows).  Children are
-// referenced like BvhNode's; unused slots hold kBvhSentinel.
+//   [origin[a] + lo(a, c) * step[a], origin[a] + hi(a, c) * step[a]]
+// with lo rounded down and hi rounded up (the box only grows); step[a] is a power
+// of two.  Children are referenced like BvhNode's; unused slots hold kBvhSentinel.
+// Nodes are stored in pre-order, so an inner child's index is always larger than
+// its parent's: following child references cannot loop.
+// Read as four 16-byte rows: (origin, step x) (qlo[3], qhi x) (qhi y, qhi z, step y, step z) (child[4]).
 struct alignas(64) WideNode {
     float origin[3];
-    uint32_t exponents; // byte a = biased f32 exponent of axis a's grid step, >= 1
+    float step_x;
     uint32_t qlo[3];    // byte c of qlo[a] = lo(a, c)
     uint32_t qhi[3];
-    uint32_t pad[2];
-    int32_t child[4];   // the last 16-byte row
+    float step_yz[2];
+    int32_t child[4];
 };
 static_assert(sizeof(WideNode) == 64 && offsetof(WideNode, child) == 48 && offsetof(WideNode, qlo) == 16 &&
-                  offsetof(WideNode, qhi) == 28,
+                  offsetof(WideNode, qhi) == 28 && offsetof(WideNode, step_yz) == 40,
               "WideNode rows are read as four float4");
 constexpr int kLeafMaxTris = 8;
 constexpr int kBvhMaxDepth = 60; // builder guarantee; traversal stack holds 64
