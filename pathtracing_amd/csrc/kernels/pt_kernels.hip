@@ -16,6 +16,7 @@
 #include "pt_kernels.h"
 
 #include <algorithm>
+#include <cstring>
 
 namespace ptk {
 
@@ -85,6 +86,43 @@ struct SegmentBuffers {
     float* hit_c;
 };
 
+// The scene's first mesh node as seen by the kernels that queue rays: they list
+// its BVH searches for the rays they emit (see jobs_kernel), which saves the next
+// segment a pass over the queue.
+struct FirstTarget {
+    MeshTarget target;
+    float4 *job_a, *job_b, *job_c;
+    uint32_t* job_counts;
+    float4* res;
+    unsigned long long* search_total;
+    uint32_t enabled;
+};
+
+// Lists the search of `ray` (queued at record `item` of the wave's region, `queued`
+// = this lane queued a ray) against the first mesh node, or stores its "no triangle"
+// result.  Wave-uniform control flow; `job_pos` counts the region's jobs.
+__device__ __forceinline__ void list_first_search(const DScene& scene, const FirstTarget& ft, bool queued, const Ray& world,
+                                                  size_t base, uint32_t item, uint32_t& job_pos,
+                                                  unsigned long long lane_lt) {
+    bool need = false;
+    Ray ray = world;
+    if (queued) {
+        ConstNodePtr nodes = const_nodes(scene);
+        for (uint32_t c = 0; c < ft.target.chain_len; c++) ray = transform_ray_c(nodes[ft.target.chain[c]], ray);
+        need = trav_reaches(scene.meshes[ft.target.mesh_id], ray);
+        if (!need)
+            ft.res[base + item] = make_float4(f32_inf(), __uint_as_float(0u), __uint_as_float(0u), __uint_as_float(0xFFFFFFFFu));
+    }
+    const unsigned long long mask = __ballot(need);
+    if (need) {
+        size_t j = base + job_pos + (uint32_t)__popcll(mask & lane_lt);
+        ft.job_a[j] = make_float4(ray.source.x, ray.source.y, ray.source.z, ray.min);
+        ft.job_b[j] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, ray.max);
+        ft.job_c[j] = make_float4(__uint_as_float(item), __uint_as_float(ft.target.mesh_id), 0.0f, 0.0f);
+    }
+    job_pos += (uint32_t)__popcll(mask);
+}
+
 // -------------------------------------------------------------- camera kernel
 // Camera::get_ray (camera.rs:51-83) for every path of the batch: path slot ->
 // (sample, pixel), the first draws of the path's random stream, the ray into the
@@ -105,7 +143,7 @@ __host__ __device__ inline uint32_t camera_xcd_classes(uint32_t regions, uint32_
 }
 
 __global__ void __launch_bounds__(kBlock)
-camera_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions) {
+camera_kernel(RenderParams p, SegmentBuffers b, FirstTarget ft, uint32_t cap, uint32_t regions) {
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
@@ -114,9 +152,10 @@ camera_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions) 
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     const uint32_t xcds = camera_xcd_classes(regions, p.geo.nby);
     const uint32_t regions_per_xcd = regions / xcds;
+    unsigned long long listed = 0;
     for (uint32_t r = wave; r < regions; r += waves) {
         const size_t base = (size_t)r * cap;
-        uint32_t out_pos = 0u;
+        uint32_t out_pos = 0u, job_pos = 0u;
         // region r belongs to workgroup r / 4, whose XCD class is (r / 4) mod 8
         const uint32_t xcd = (r / kWavesPerBlock) % xcds;
         const uint32_t index_in_xcd = (r / (kWavesPerBlock * xcds)) * kWavesPerBlock + (r % kWavesPerBlock);
@@ -143,16 +182,23 @@ camera_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions) 
                 }
             }
             unsigned long long mask = __ballot(have);
+            const uint32_t item = out_pos + (uint32_t)__popcll(mask & lane_lt);
             if (have) {
-                size_t o = base + out_pos + (uint32_t)__popcll(mask & lane_lt);
+                size_t o = base + item;
                 b.ray_a[o] = make_float4(ray.source.x, ray.source.y, ray.source.z, ray.min);
                 b.ray_b[o] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, __uint_as_float((uint32_t)slot));
                 b.ray_c[o] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng_counter));
             }
+            if (ft.enabled) list_first_search(p.scene, ft, have, ray, base, item, job_pos, lane_lt);
             out_pos += (uint32_t)__popcll(mask);
         }
-        if (lane == 0u) b.ray_counts[r] = out_pos;
+        if (lane == 0u) {
+            b.ray_counts[r] = out_pos;
+            if (ft.enabled) ft.job_counts[r] = job_pos;
+        }
+        listed += job_pos;
     }
+    if (lane == 0u && listed) atomicAdd(ft.search_total, listed);
 }
 
 // ---------------------------------------------------------------- jobs kernel
@@ -289,17 +335,19 @@ walk_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions, un
 // wave's region of the other queue, or the path's final colour into the
 // contribution buffer.
 __global__ void __launch_bounds__(kBlock)
-bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, uint32_t cap, uint32_t regions, float* contrib) {
+bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, FirstTarget ft, uint32_t cap, uint32_t regions,
+              float* contrib) {
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
     const uint32_t waves = (gridDim.x * kBlock) >> 6;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    unsigned long long listed = 0;
 
     for (uint32_t r = wave; r < regions; r += waves) {
         const size_t base = (size_t)r * cap;
         const uint32_t n_items = b.ray_counts[r];
-        uint32_t out_pos = 0u;
+        uint32_t out_pos = 0u, job_pos = 0u;
         for (uint32_t first = 0; first < n_items; first += 64u) {
             const uint32_t item = first + lane;
             bool emit = false;
@@ -358,16 +406,23 @@ bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, uint32_t cap, ui
             }
             // surviving paths go to this region of the next segment's queue
             unsigned long long emit_mask = __ballot(emit);
+            const uint32_t next_item = out_pos + (uint32_t)__popcll(emit_mask & lane_lt);
             if (emit) {
-                size_t slot = base + out_pos + (uint32_t)__popcll(emit_mask & lane_lt);
+                size_t slot = base + next_item;
                 b.next_a[slot] = make_float4(nray.source.x, nray.source.y, nray.source.z, nray.min);
                 b.next_b[slot] = make_float4(nray.direction.x, nray.direction.y, nray.direction.z, __uint_as_float(path));
                 b.next_c[slot] = make_float4(nmult.x, nmult.y, nmult.z, __uint_as_float(rng_counter));
             }
+            if (ft.enabled && emit_mask != 0ull) list_first_search(p.scene, ft, emit, nray, base, next_item, job_pos, lane_lt);
             out_pos += (uint32_t)__popcll(emit_mask);
         }
-        if (lane == 0u) b.next_counts[r] = out_pos;
+        if (lane == 0u) {
+            b.next_counts[r] = out_pos;
+            if (ft.enabled) ft.job_counts[r] = job_pos;
+        }
+        listed += job_pos;
     }
+    if (lane == 0u && listed) atomicAdd(ft.search_total, listed);
 }
 
 // -------------------------------------------------------------- search kernel
@@ -649,11 +704,25 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
         b.hit_c = ws.hit_uv_y;
         return b;
     };
-    camera_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, buffers(0), cap, regions);
+    // the kernels that queue rays list the searches of the first mesh node themselves
+    FirstTarget ft;
+    memset(&ft, 0, sizeof(ft));
+    if (searched) {
+        ft.target = targets[0];
+        ft.job_a = ws.jobs[0];
+        ft.job_b = ws.jobs[1];
+        ft.job_c = ws.jobs[2];
+        ft.job_counts = ws.job_counts;
+        ft.res = ws.results[0];
+        ft.search_total = rt + 1;
+        ft.enabled = 1u;
+    }
+    camera_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, buffers(0), ft, cap, regions);
     for (uint32_t d = 0; d < trace_depth; d++) {
         SegmentBuffers b = buffers((int)(d & 1u));
         for (uint32_t m = 0; m < searched; m++) {
-            jobs_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(scene, targets[m], b.ray_a, b.ray_b, b.ray_counts,
+            if (m > 0)
+                jobs_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(scene, targets[m], b.ray_a, b.ray_b, b.ray_counts,
                                                                      ws.jobs[0], ws.jobs[1], ws.jobs[2], ws.job_counts,
                                                                      ws.results[m], rt + 1, cap, regions);
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -670,7 +739,7 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
             if (search_events && (e = hipEventRecord(e1, stream)) != hipSuccess) return e;
         }
         walk_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, b, cap, regions, rt, ws.spill, spill_threads);
-        bounce_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, b, cap, regions, ws.contrib);
+        bounce_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, b, ft, cap, regions, ws.contrib);
     }
     accumulate_kernel<<<blocks_for(geo.npp), kBlock, 0, stream>>>(geo, cam.width, sample_count, ws.contrib, d_accum);
     return hipGetLastError();
