@@ -26,7 +26,7 @@ struct Workspace {
     // triangle of the scene's m-th mesh node for each ray, indexed like a queue
     float4* jobs[3] = {nullptr, nullptr, nullptr};
     uint32_t* job_counts = nullptr;
-    float4* results[4] = {nullptr, nullptr, nullptr, nullptr};
+    float4* results[16] = {};
     // the segment's hit per ray, indexed like a queue: (point, material | inside << 31) (normal, uv.x), uv.y
     float4* hits[2] = {nullptr, nullptr};
     float* hit_uv_y = nullptr;
@@ -46,7 +46,8 @@ uint32_t segment_blocks_per_cu(); // resident blocks per compute unit the trace 
 uint32_t queue_region_capacity(uint32_t nbx, uint32_t nby, uint32_t samples, uint32_t waves);
 constexpr uint32_t kTraceBlock = 256;
 
-constexpr int kMaxDeferred = 4; // mesh nodes of a scene whose searches go through the search kernel
+constexpr int kMaxDeferred = 16; // mesh nodes of a scene whose searches go through the search kernel
+static_assert(sizeof(Workspace::results) / sizeof(float4*) == kMaxDeferred, "one result array per searched mesh node");
 
 struct BatchGeometry {
     uint32_t x0, y0, w, h; // pixel rectangle, camera space

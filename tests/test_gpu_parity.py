@@ -143,3 +143,40 @@ def test_wire_bytes():
     assert raw[:8] == bytes.fromhex("0200000001000000")
     assert np.array_equal(np.frombuffer(raw[8:], dtype="<f4"), np.arange(1, 7, dtype=np.float32))
     assert np.array_equal(P.RenderedImage.from_bytes(raw).image, img)
+
+
+def test_more_mesh_nodes_than_result_arrays(oracle, tmp_path):
+    """Twenty mesh nodes: the first sixteen are searched ahead of the walk, the last
+    four inside the walk kernel.  Closest hits and a small render against the oracle."""
+    import json
+    import shutil
+
+    root = str(tmp_path / "many")
+    shutil.copytree(H.SCENE_DATA, root)
+    children = [{"type": "sphere", "center": [0.0, 9.0, 0.0], "radius": 3.0, "material": "./materials/mat0.json"}]
+    for i in range(20):
+        x, z = (i % 5 - 2) * 2.6, (i // 5 - 1.5) * 2.6
+        m = [[0.5, 0.0, 0.0, x], [0.0, 0.5 + 0.05 * i, 0.0, -1.0], [0.0, 0.0, 0.5, z], [0.0, 0.0, 0.0, 1.0]]
+        children.append({"type": "transform", "matrix": m,
+                         "child": {"type": "mesh", "path": "./cube.obj", "material": f"./materials/mat{1 + i % 5}.json"}})
+    children.append({"type": "plane", "point": [0.0, -3.0, 0.0], "normal": [0.0, 1.0, 0.0], "tangent": [0.0, 0.0, -1.0],
+                     "bitangent": [1.0, 0.0, 0.0], "material": "./materials/mat2.json"})
+    with open(os.path.join(root, "many.json"), "w") as f:
+        json.dump({"type": "node_collection", "children": children}, f)
+    scene = P.Scene.load(root, "./many.json")
+    gpu = P.HipRenderer.init(scene, 0)
+    cpu = oracle.scene(scene.desc_pointer)
+    rays = H.random_rays(100_000, seed=41, origin_box=9.0, target_box=6.0)
+    want = cpu.trace(rays, accel=ob.ACCEL_LINEAR, math=ob.MATH_PORTABLE)
+    H.assert_hits_identical(gpu.trace_closest(rays), want, "twenty meshes")
+    hit_nodes = np.unique(want["node_index"][(want["hit"] == 1) & (want["tri_index"] != 0xFFFFFFFF)])
+    assert hit_nodes.size == 20
+    task = H.load_task()
+    task.camera.resolution = [80, 60]
+    task.config.iterations = 3
+    got = gpu.render(task, P.RenderOpts(seed=8))
+    ref, st = cpu.render(task, P.RenderOpts(seed=8), accel=ob.ACCEL_LINEAR, math=ob.MATH_PORTABLE)
+    assert gpu.last_stats.rays == st.rays
+    assert np.array_equal(H.bits(got), H.bits(ref))
+    gpu.close()
+    cpu.close()
