@@ -124,3 +124,56 @@ def test_instanced_dragons_through_the_scene_graph(oracle, dragon_dir):
     assert np.array_equal(H.bits(got), H.bits(ref))
     gpu.close()
     cpu.close()
+
+
+def test_flattened_instances_seven_million_triangles(oracle, dragon_dir):
+    """The instanced workload the other way round: eight copies of the 871k-triangle
+    mesh flattened into one mesh of 7.0 M world-space triangles behind the dragon
+    scene's graph (one BVH of 2.9 M leaves).  Closest hits against the oracle's own
+    BVH over the same triangles, and the tree's structural check."""
+    import ctypes as C
+
+    from pathtracing_amd import _native as N
+    from pathtracing_amd.scene import build_tree, validate_tree
+
+    out, task_path = dragon_dir
+    task = H.load_task(task_path)
+    scene = P.Scene.load(out, task.scene)
+    base = scene.desc
+    assert base.mesh_count == 1
+    n1 = int(base.meshes[0].triangle_count)
+    one = np.ctypeslib.as_array(base.meshes[0].positions, shape=(n1, 9))
+    copies = []
+    for i in range(8):
+        shift = np.array([26.0 * (i % 4 - 1.5), 0.0, -40.0 * (i // 4)], dtype=np.float32)
+        copies.append(one + np.tile(shift, 3))
+    positions = np.ascontiguousarray(np.concatenate(copies), dtype=np.float32)
+    mesh = N.PtMeshDesc()
+    mesh.triangle_count = positions.shape[0]
+    mesh.positions = positions.ctypes.data_as(C.POINTER(C.c_float))
+    big = N.PtSceneDesc()
+    for name, _ in N.PtSceneDesc._fields_:
+        setattr(big, name, getattr(base, name))
+    big.meshes = C.pointer(mesh)
+    big.mesh_count = 1
+    # the tree the library builds passes its own structural and conservativeness check
+    blob = build_tree(mesh)
+    assert validate_tree(mesh, blob)
+    gpu = P.HipRenderer.from_desc(C.pointer(big), 0)
+    cpu = oracle.scene(C.pointer(big))
+    rng = np.random.default_rng(29)
+    n = 300_000
+    src = np.stack([rng.uniform(-60, 60, n), rng.uniform(-14, 14, n), rng.uniform(-60, 70, n)], axis=1)
+    dst = np.stack([rng.uniform(-50, 50, n), rng.uniform(-12, 8, n), rng.uniform(-50, 10, n)], axis=1)
+    d = dst - src
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, :3], rays[:, 3:6], rays[:, 7] = src, d, H.F32_MAX
+    want = cpu.trace(rays, accel=ob.ACCEL_BVH, math=ob.MATH_PORTABLE)
+    got = gpu.trace_closest(rays)
+    H.assert_hits_identical(got, want, "flattened instances")
+    on_mesh = (want["hit"] == 1) & (want["tri_index"] != 0xFFFFFFFF)
+    assert on_mesh.mean() > 0.2
+    assert np.unique(want["tri_index"][on_mesh] // n1).size == 8  # every copy is hit
+    gpu.close()
+    cpu.close()
