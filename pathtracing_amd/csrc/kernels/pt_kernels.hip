@@ -334,7 +334,10 @@ walk_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions, un
 // hit the walk kernel found, texel fetch, then the next segment's ray into the
 // wave's region of the other queue, or the path's final colour into the
 // contribution buffer.
-__global__ void __launch_bounds__(kBlock)
+#ifndef PT_BOUNCE_OCCUPANCY
+#define PT_BOUNCE_OCCUPANCY 4
+#endif
+__global__ void __launch_bounds__(kBlock, PT_BOUNCE_OCCUPANCY)
 bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, FirstTarget ft, uint32_t cap, uint32_t regions,
               float* contrib) {
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
