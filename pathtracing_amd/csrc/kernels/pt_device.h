@@ -610,7 +610,10 @@ __device__ __forceinline__ V3 mul_point_c(const __attribute__((address_space(4))
     V3 r = mk3(p.x * a.m[0][0] + p.y * a.m[0][1] + p.z * a.m[0][2] + 1.0f * a.m[0][3],
                p.x * a.m[1][0] + p.y * a.m[1][1] + p.z * a.m[1][2] + 1.0f * a.m[1][3],
                p.x * a.m[2][0] + p.y * a.m[2][1] + p.z * a.m[2][2] + 1.0f * a.m[2][3]);
-    return r / w;
+    // x / 1.0 is x for every x, so the three divisions are skipped when w is exactly 1 (affine
+    // matrices and finite points; a non-finite point makes w NaN and takes the division)
+    if (w != 1.0f) r = r / w;
+    return r;
 }
 __device__ __forceinline__ V3 mul_c(const __attribute__((address_space(4))) M3& a, V3 rhs) {
     return mk3(dot(rhs, cv3(a.row0)), dot(rhs, cv3(a.row1)), dot(rhs, cv3(a.row2)));
