@@ -548,7 +548,15 @@ __device__ __forceinline__ void mesh_result(const DMesh& mesh, const DNode& n, u
     out->tri_index = found ? orig : 0xFFFFFFFFu;
     if (found) {
         LeafTri tr = load_tri(tri);
-        ShadeTri sh = mesh.shade[orig];
+        GlobalF4Ptr q = global_f4(mesh.shade + orig); // 80 bytes = five rows
+        float4 s0 = q[0], s1 = q[1], s2 = q[2], s3 = q[3], s4 = q[4];
+        ShadeTri sh;
+        sh.true_normal[0] = s0.x; sh.true_normal[1] = s0.y; sh.true_normal[2] = s0.z;
+        sh.n0[0] = s0.w; sh.n0[1] = s1.x; sh.n0[2] = s1.y;
+        sh.n1[0] = s1.z; sh.n1[1] = s1.w; sh.n1[2] = s2.x;
+        sh.n2[0] = s2.y; sh.n2[1] = s2.z; sh.n2[2] = s2.w;
+        sh.uv0[0] = s3.x; sh.uv0[1] = s3.y; sh.uv1[0] = s3.z; sh.uv1[1] = s3.w;
+        sh.uv2[0] = s4.x; sh.uv2[1] = s4.y;
         triangle_finish(tr, sh, ray, t, out);
     }
 }
@@ -806,7 +814,7 @@ __device__ __forceinline__ V3 sample_color(const DMaterial& m, V2 uv) {
     uint32_t x = f32_as_u32(coords.x), y = f32_as_u32(coords.y);
     if (x >= m.tex_w) x = m.tex_w - 1u;
     if (y >= m.tex_h) y = m.tex_h - 1u;
-    uint32_t texel = reinterpret_cast<const uint32_t*>(m.texels)[(size_t)y * m.tex_w + x];
+    uint32_t texel = ((const __attribute__((address_space(1))) uint32_t*)(unsigned long long)m.texels)[(size_t)y * m.tex_w + x];
     return mk3((float)(texel & 0xFFu) / 256.0f, (float)((texel >> 8) & 0xFFu) / 256.0f,
                (float)((texel >> 16) & 0xFFu) / 256.0f);
 }
