@@ -265,9 +265,7 @@ void build_mesh(PtScene& s, const PtMeshDesc& m, const PtTreeBlob* blob, ptk::DM
     pt::BuiltBvh bvh;
     bool adopted = false;
     if (blob && blob->size && blob->data) adopted = pt::deserialize_tree(blob->data, blob->size, m.positions, n, &bvh);
-    uint32_t max_leaf = 4;
-    if (const char* e = getenv("PT_EXPERIMENT_MAX_LEAF")) max_leaf = (uint32_t)atoi(e); // tuning experiments only
-    if (!adopted) bvh = pt::build_bvh(m.positions, n, max_leaf);
+    if (!adopted) bvh = pt::build_bvh(m.positions, n, 4); // leaves of 2..4 triangles render equally fast, 1 and 6+ slower
 
     std::vector<ptk::LeafTri> leaf(n), orig(n);
     std::vector<ptk::ShadeTri> shade(n);
