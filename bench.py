@@ -187,6 +187,10 @@ def main():
         torch.cuda.synchronize()
         if args.no_cpu_baseline:
             ref, bvh, stats = None, None, None
+        elif multi:
+            # the CPU legs run at N = 1 only; the per-ray statistics of the workload do not
+            # depend on N and are taken from the record of an N = 1 run
+            ref, bvh, stats = None, None, recorded_ray_statistics()
         else:
             ref, bvh, stats = cpu_legs(scene, task)
         roofline = None
@@ -225,6 +229,14 @@ def main():
         dist.destroy_process_group()
     if result is not None:
         print(json.dumps(result), flush=True)
+
+
+def recorded_ray_statistics():
+    try:
+        with open(os.path.join(ROOT, "profiles", "ray_statistics.json")) as f:
+            return json.load(f).get("ray_statistics")
+    except (OSError, ValueError):
+        return None
 
 
 def measured_traffic():
