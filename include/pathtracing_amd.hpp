@@ -1,0 +1,146 @@
+// C++ host mirror of the reference worker's rendering interface, over the C ABI
+// of pathtracing_amd.h (header only; link with -lpathtracing_amd).
+//
+//   pt::Scene        Arc<Scene>       worker/src/scene/mod.rs:27-112  (Scene::load)
+//   pt::RenderTask   RenderTask       worker/src/api/render_task.rs:23-49
+//   pt::HipRenderer  impl Renderer    worker/src/renderer/mod.rs:9-13 (init / render)
+//   pt::RenderedImage                 worker/src/lib.rs:51-79         (to_bytes)
+//   pt::Worker       Worker           worker/src/lib.rs:20-48         (scene cache + render)
+//
+// Where the reference panics (missing file, malformed JSON, ...) these throw pt::Failure.
+#ifndef PATHTRACING_AMD_HPP
+#define PATHTRACING_AMD_HPP
+
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "pathtracing_amd.h"
+
+namespace pt {
+
+class Failure : public std::runtime_error {
+public:
+    Failure(PtStatus status, const std::string& what) : std::runtime_error(what), status_(status) {}
+    PtStatus status() const { return status_; }
+
+private:
+    PtStatus status_;
+};
+
+inline void check(PtStatus status) {
+    if (status == PT_OK) return;
+    std::string msg(pt_last_error(nullptr, 0) + 1, '\0');
+    pt_last_error(&msg[0], msg.size());
+    msg.resize(msg.size() - 1);
+    throw Failure(status, msg);
+}
+
+// Scene::load: the scene JSON and every resource it references, from a local directory.
+class Scene {
+public:
+    static std::shared_ptr<Scene> load(const std::string& root_dir, const std::string& scene_path) {
+        PtHostScene* h = nullptr;
+        check(pt_host_scene_load(root_dir.c_str(), scene_path.c_str(), &h));
+        return std::shared_ptr<Scene>(new Scene(h));
+    }
+    ~Scene() { pt_host_scene_destroy(handle_); }
+    Scene(const Scene&) = delete;
+    Scene& operator=(const Scene&) = delete;
+    const PtSceneDesc* desc() const { return pt_host_scene_desc(handle_); }
+
+private:
+    explicit Scene(PtHostScene* h) : handle_(h) {}
+    PtHostScene* handle_;
+};
+
+struct RenderTask {
+    std::string scene; // path of the scene JSON, as in the task
+    PtRenderTask task{};
+
+    static RenderTask from_json(const std::string& text) {
+        RenderTask t;
+        char path[4096];
+        check(pt_render_task_parse(text.c_str(), &t.task, path, sizeof(path)));
+        t.scene = path;
+        return t;
+    }
+};
+
+// Rgb32FImage + the bytes the worker sends back.
+struct RenderedImage {
+    uint32_t width = 0, height = 0;
+    std::vector<float> rgb; // row-major, top row first, 3 floats per pixel
+
+    std::vector<uint8_t> to_bytes() const {
+        std::vector<uint8_t> out(8 + rgb.size() * sizeof(float));
+        check(pt_rendered_image_to_bytes(rgb.data(), width, height, out.data(), out.size()));
+        return out;
+    }
+};
+
+// trait Renderer { fn init(scene: Arc<Scene>) -> Self; async fn render(&mut self, task) -> Rgb32FImage }
+class HipRenderer {
+public:
+    static HipRenderer init(std::shared_ptr<const Scene> scene, int device = 0) {
+        PtScene* h = nullptr;
+        check(pt_scene_create(scene->desc(), device, &h));
+        return HipRenderer(h, std::move(scene));
+    }
+    HipRenderer(HipRenderer&& o) noexcept : handle_(o.handle_), scene_(std::move(o.scene_)) { o.handle_ = nullptr; }
+    HipRenderer& operator=(HipRenderer&& o) noexcept {
+        if (this != &o) {
+            pt_scene_destroy(handle_);
+            handle_ = o.handle_;
+            scene_ = std::move(o.scene_);
+            o.handle_ = nullptr;
+        }
+        return *this;
+    }
+    HipRenderer(const HipRenderer&) = delete;
+    HipRenderer& operator=(const HipRenderer&) = delete;
+    ~HipRenderer() { pt_scene_destroy(handle_); }
+
+    RenderedImage render(const RenderTask& task, const PtRenderOpts* opts = nullptr, PtRenderStats* stats = nullptr) {
+        RenderedImage img;
+        img.width = (uint32_t)task.task.camera.resolution_x;
+        img.height = (uint32_t)task.task.camera.resolution_y;
+        img.rgb.resize((size_t)img.width * img.height * 3);
+        check(pt_render(handle_, &task.task, opts, img.rgb.data(), stats));
+        return img;
+    }
+
+private:
+    HipRenderer(PtScene* h, std::shared_ptr<const Scene> s) : handle_(h), scene_(std::move(s)) {}
+    PtScene* handle_;
+    std::shared_ptr<const Scene> scene_;
+};
+
+// Worker::render (lib.rs:31-48): loads the task's scene unless it is the one already held, renders.
+// The reference keys its cache on scene_md5; a local directory has no md5, so the scene path is the key,
+// and the renderer (BVH + device copies) is kept with the scene instead of being rebuilt per task.
+class Worker {
+public:
+    explicit Worker(std::string root_dir, int device = 0) : root_(std::move(root_dir)), device_(device) {}
+
+    RenderedImage render(const RenderTask& task, const PtRenderOpts* opts = nullptr, PtRenderStats* stats = nullptr) {
+        if (!renderer_ || task.scene != scene_path_) {
+            renderer_.reset();
+            auto scene = Scene::load(root_, task.scene);
+            renderer_.reset(new HipRenderer(HipRenderer::init(scene, device_)));
+            scene_path_ = task.scene;
+        }
+        return renderer_->render(task, opts, stats);
+    }
+
+private:
+    std::string root_, scene_path_;
+    int device_;
+    std::unique_ptr<HipRenderer> renderer_;
+};
+
+} // namespace pt
+#endif
