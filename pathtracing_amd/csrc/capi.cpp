@@ -109,6 +109,7 @@ struct PtScene {
         ws.contrib = nullptr;
         ws.capacity_paths = 0;
         ws.contrib_paths = 0;
+        ws.job_records = 0;
     }
     // Fixed state of the trace kernels: the spill columns and per-wave queue
     // counters of the persistent grid (4 blocks of 256 threads per compute unit).
@@ -138,9 +139,10 @@ struct PtScene {
             for (int k = 0; k < 3; k++)
                 hip_check(hipMalloc(reinterpret_cast<void**>(&ws.queue[q][k]), records * sizeof(float4)), "hipMalloc queue");
         uint32_t result_arrays = std::min<uint32_t>((uint32_t)targets.size(), (uint32_t)ptk::kMaxDeferred);
+        ws.job_records = records * result_arrays;
         if (result_arrays)
             for (int k = 0; k < 3; k++)
-                hip_check(hipMalloc(reinterpret_cast<void**>(&ws.jobs[k]), records * sizeof(float4)), "hipMalloc jobs");
+                hip_check(hipMalloc(reinterpret_cast<void**>(&ws.jobs[k]), ws.job_records * sizeof(float4)), "hipMalloc jobs");
         for (uint32_t k = 0; k < result_arrays; k++)
             hip_check(hipMalloc(reinterpret_cast<void**>(&ws.results[k]), records * sizeof(float4)), "hipMalloc results");
         for (int k = 0; k < 2; k++)
@@ -542,6 +544,8 @@ PtStatus pt_scene_create(const PtSceneDesc* desc, int device, PtScene** out_scen
         s->d.materials = s->upload(mats);
         s->d.mesh_count = desc->mesh_count;
         s->d.material_count = desc->material_count;
+        s->d.targets = s->upload(s->targets);
+        s->d.target_count = (uint32_t)s->targets.size();
         hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
         *out_scene = s.release();
     });

@@ -21,11 +21,14 @@ namespace ptk {
 struct Workspace {
     float4* queue[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     uint32_t* wave_counts[2] = {nullptr, nullptr};
-    // BVH search requests of the mesh node being searched (three rows per request,
-    // regions like a queue) with their per-region counts; results[m] = closest
-    // triangle of the scene's m-th mesh node for each ray, indexed like a queue
+    // BVH search requests of the segment (three rows per request; one region per wave,
+    // sized for every ray reaching every mesh node that is searched ahead of the walk)
+    // with their per-region counts; job_records = records each array holds.
+    // results[m] = closest triangle of the scene's m-th mesh node for each ray, indexed
+    // like a queue
     float4* jobs[3] = {nullptr, nullptr, nullptr};
     uint32_t* job_counts = nullptr;
+    uint64_t job_records = 0;
     float4* results[16] = {};
     // the segment's hit per ray, indexed like a queue: (point, material | inside << 31) (normal, uv.x), uv.y
     float4* hits[2] = {nullptr, nullptr};

@@ -2,8 +2,9 @@
 //
 // One batch = some consecutive samples of every pixel of a rectangle.  Per batch:
 //   camera_kernel        the batch's camera rays
-//   per path segment:    jobs_kernel + search_kernel for each mesh node of the
-//                        scene graph (closest triangle per ray), walk_kernel
+//   per path segment:    search_kernel (closest triangle per ray and mesh node; the
+//                        searches were listed by the kernel that queued the rays:
+//                        camera_kernel or the previous bounce_kernel), walk_kernel
 //                        (scene-graph walk: the segment's hit), bounce_kernel
 //                        (material sampling; survivors go to the wave's region of
 //                        the other queue, finished paths store their colour into
@@ -86,41 +87,53 @@ struct SegmentBuffers {
     float* hit_c;
 };
 
-// The scene's first mesh node as seen by the kernels that queue rays: they list
-// its BVH searches for the rays they emit (see jobs_kernel), which saves the next
-// segment a pass over the queue.
-struct FirstTarget {
-    MeshTarget target;
+// Where the kernels that queue rays list the BVH searches of those rays: one job per
+// (ray, mesh node whose bounds the ray reaches), appended to the wave's region of the
+// job list; job_cap records per region (a ray can reach every listed mesh node).
+//   job = (object-space source,min) (direction,max) (ray's record in the region, mesh id, ordinal of the mesh node, -)
+struct SearchList {
     float4 *job_a, *job_b, *job_c;
     uint32_t* job_counts;
-    float4* res;
     unsigned long long* search_total;
-    uint32_t enabled;
+    uint32_t count;   // mesh nodes listed: the scene's first `count` (0: nothing is searched ahead of the walk)
+    uint32_t job_cap; // job records per region
 };
 
-// Lists the search of `ray` (queued at record `item` of the wave's region, `queued`
-// = this lane queued a ray) against the first mesh node, or stores its "no triangle"
-// result.  Wave-uniform control flow; `job_pos` counts the region's jobs.
-__device__ __forceinline__ void list_first_search(const DScene& scene, const FirstTarget& ft, bool queued, const Ray& world,
-                                                  size_t base, uint32_t item, uint32_t& job_pos,
-                                                  unsigned long long lane_lt) {
-    bool need = false;
-    Ray ray = world;
-    if (queued) {
-        ConstNodePtr nodes = const_nodes(scene);
-        for (uint32_t c = 0; c < ft.target.chain_len; c++) ray = transform_ray_c(nodes[ft.target.chain[c]], ray);
-        need = trav_reaches(scene.meshes[ft.target.mesh_id], ray);
-        if (!need)
-            ft.res[base + item] = make_float4(f32_inf(), __uint_as_float(0u), __uint_as_float(0u), __uint_as_float(0xFFFFFFFFu));
+typedef const __attribute__((address_space(4))) MeshTarget* ConstTargetPtr;
+
+// Lists the searches of `world` (queued at record `item` of the wave's region r,
+// `queued` = this lane queued a ray): per mesh node, the ray goes through the
+// transform nodes above the mesh (the arithmetic the walk kernel repeats later,
+// transform.rs:45-48); if it can reach the mesh it becomes a job, otherwise its "no
+// triangle" result is stored right here.  Wave-uniform control flow; `job_pos`
+// counts the region's jobs.
+__device__ __forceinline__ void list_searches(const DScene& scene, const SearchList& sl, float4* const* res, bool queued,
+                                              const Ray& world, uint32_t r, uint32_t cap, uint32_t item, uint32_t& job_pos,
+                                              unsigned long long lane_lt) {
+    ConstNodePtr nodes = const_nodes(scene);
+    ConstTargetPtr targets = (ConstTargetPtr)(unsigned long long)scene.targets;
+    const size_t job_base = (size_t)r * sl.job_cap;
+    for (uint32_t m = 0; m < sl.count; m++) {
+        bool need = false;
+        Ray ray = world;
+        const uint32_t mesh_id = targets[m].mesh_id;
+        if (queued) {
+            const uint32_t chain_len = targets[m].chain_len;
+            for (uint32_t c = 0; c < chain_len; c++) ray = transform_ray_c(nodes[targets[m].chain[c]], ray);
+            need = trav_reaches(scene.meshes[mesh_id], ray);
+            if (!need)
+                res[m][(size_t)r * cap + item] =
+                    make_float4(f32_inf(), __uint_as_float(0u), __uint_as_float(0u), __uint_as_float(0xFFFFFFFFu));
+        }
+        const unsigned long long mask = __ballot(need);
+        if (need) {
+            size_t j = job_base + job_pos + (uint32_t)__popcll(mask & lane_lt);
+            sl.job_a[j] = make_float4(ray.source.x, ray.source.y, ray.source.z, ray.min);
+            sl.job_b[j] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, ray.max);
+            sl.job_c[j] = make_float4(__uint_as_float(item), __uint_as_float(mesh_id), __uint_as_float(m), 0.0f);
+        }
+        job_pos += (uint32_t)__popcll(mask);
     }
-    const unsigned long long mask = __ballot(need);
-    if (need) {
-        size_t j = base + job_pos + (uint32_t)__popcll(mask & lane_lt);
-        ft.job_a[j] = make_float4(ray.source.x, ray.source.y, ray.source.z, ray.min);
-        ft.job_b[j] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, ray.max);
-        ft.job_c[j] = make_float4(__uint_as_float(item), __uint_as_float(ft.target.mesh_id), 0.0f, 0.0f);
-    }
-    job_pos += (uint32_t)__popcll(mask);
 }
 
 // -------------------------------------------------------------- camera kernel
@@ -143,7 +156,7 @@ __host__ __device__ inline uint32_t camera_xcd_classes(uint32_t regions, uint32_
 }
 
 __global__ void __launch_bounds__(kBlock)
-camera_kernel(RenderParams p, SegmentBuffers b, FirstTarget ft, uint32_t cap, uint32_t regions) {
+camera_kernel(RenderParams p, SegmentBuffers b, SearchList sl, uint32_t cap, uint32_t regions) {
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
@@ -189,69 +202,16 @@ camera_kernel(RenderParams p, SegmentBuffers b, FirstTarget ft, uint32_t cap, ui
                 b.ray_b[o] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, __uint_as_float((uint32_t)slot));
                 b.ray_c[o] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng_counter));
             }
-            if (ft.enabled) list_first_search(p.scene, ft, have, ray, base, item, job_pos, lane_lt);
+            if (sl.count) list_searches(p.scene, sl, b.res, have, ray, r, cap, item, job_pos, lane_lt);
             out_pos += (uint32_t)__popcll(mask);
         }
         if (lane == 0u) {
             b.ray_counts[r] = out_pos;
-            if (ft.enabled) ft.job_counts[r] = job_pos;
+            if (sl.count) sl.job_counts[r] = job_pos;
         }
         listed += job_pos;
     }
-    if (lane == 0u && listed) atomicAdd(ft.search_total, listed);
-}
-
-// ---------------------------------------------------------------- jobs kernel
-// Prepares the BVH searches of one mesh node for every ray of the segment: takes
-// the ray through the transform nodes above the mesh (the arithmetic the walk
-// kernel repeats later, transform.rs:45-48), rejects rays that cannot reach the
-// mesh and appends the others to the job list of the wave's region:
-//   (object-space source,min) (direction,max) (ray index, mesh id, -, -)
-// A rejected ray gets its "no triangle" result right here.
-__global__ void __launch_bounds__(kBlock)
-jobs_kernel(DScene scene, MeshTarget target, const float4* __restrict__ ray_a, const float4* __restrict__ ray_b,
-            const uint32_t* __restrict__ ray_counts, float4* job_a, float4* job_b, float4* job_c, uint32_t* job_counts,
-            float4* res, unsigned long long* search_total, uint32_t cap, uint32_t regions) {
-    const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = tid >> 6;
-    const uint32_t waves = (gridDim.x * kBlock) >> 6;
-    const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    unsigned long long listed = 0;
-    ConstNodePtr nodes = const_nodes(scene);
-    const DMesh& mesh = scene.meshes[target.mesh_id];
-    for (uint32_t r = wave; r < regions; r += waves) {
-        const size_t base = (size_t)r * cap;
-        const uint32_t n_items = ray_counts[r];
-        uint32_t job_pos = 0u;
-        for (uint32_t first = 0; first < n_items; first += 64u) {
-            const uint32_t item = first + lane;
-            const bool have = item < n_items;
-            bool need = false;
-            Ray ray;
-            if (have) {
-                float4 ra = ray_a[base + item], rb = ray_b[base + item];
-                ray.source = mk3(ra.x, ra.y, ra.z);
-                ray.min = ra.w;
-                ray.direction = mk3(rb.x, rb.y, rb.z);
-                ray.max = kF32Max;
-                for (uint32_t c = 0; c < target.chain_len; c++) ray = transform_ray_c(nodes[target.chain[c]], ray);
-                need = trav_reaches(mesh, ray);
-                if (!need) res[base + item] = make_float4(f32_inf(), __uint_as_float(0u), __uint_as_float(0u), __uint_as_float(0xFFFFFFFFu));
-            }
-            unsigned long long mask = __ballot(need);
-            if (need) {
-                size_t j = base + job_pos + (uint32_t)__popcll(mask & lane_lt);
-                job_a[j] = make_float4(ray.source.x, ray.source.y, ray.source.z, ray.min);
-                job_b[j] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, ray.max);
-                job_c[j] = make_float4(__uint_as_float(item), __uint_as_float(target.mesh_id), 0.0f, 0.0f);
-            }
-            job_pos += (uint32_t)__popcll(mask);
-        }
-        if (lane == 0u) job_counts[r] = job_pos;
-        listed += job_pos;
-    }
-    if (lane == 0u && listed) atomicAdd(search_total, listed);
+    if (lane == 0u && listed) atomicAdd(sl.search_total, listed);
 }
 
 // ---------------------------------------------------------------- walk kernel
@@ -338,7 +298,7 @@ walk_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions, un
 #define PT_BOUNCE_OCCUPANCY 4
 #endif
 __global__ void __launch_bounds__(kBlock, PT_BOUNCE_OCCUPANCY)
-bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, FirstTarget ft, uint32_t cap, uint32_t regions,
+bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList sl, uint32_t cap, uint32_t regions,
               float* contrib) {
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -416,20 +376,25 @@ bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, FirstTarget ft, 
                 b.next_b[slot] = make_float4(nray.direction.x, nray.direction.y, nray.direction.z, __uint_as_float(path));
                 b.next_c[slot] = make_float4(nmult.x, nmult.y, nmult.z, __uint_as_float(rng_counter));
             }
-            if (ft.enabled && emit_mask != 0ull) list_first_search(p.scene, ft, emit, nray, base, next_item, job_pos, lane_lt);
+            if (sl.count && emit_mask != 0ull) list_searches(p.scene, sl, b.res, emit, nray, r, cap, next_item, job_pos, lane_lt);
             out_pos += (uint32_t)__popcll(emit_mask);
         }
         if (lane == 0u) {
             b.next_counts[r] = out_pos;
-            if (ft.enabled) ft.job_counts[r] = job_pos;
+            if (sl.count) sl.job_counts[r] = job_pos;
         }
         listed += job_pos;
     }
-    if (lane == 0u && listed) atomicAdd(ft.search_total, listed);
+    if (lane == 0u && listed) atomicAdd(sl.search_total, listed);
 }
 
 // -------------------------------------------------------------- search kernel
-// The BVH searches listed by jobs_kernel.  This is where the time goes, so the
+struct SearchResults {
+    float4* res[kMaxDeferred]; // per listed mesh node: closest triangle per ray, indexed like the ray queue
+};
+
+// The BVH searches listed by the kernels that queued the rays (list_searches), for
+// all mesh nodes in one launch.  This is where the time goes, so the
 // kernel carries nothing but the search: ~64 registers per lane, 8 waves per
 // SIMD to cover the latency of the dependent node fetches.  Lanes do not wait for
 // the slowest search of their wave: each lane is a small state machine and the
@@ -437,8 +402,8 @@ bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, FirstTarget ft, 
 // lengths differ by an order of magnitude between neighbouring rays).
 __global__ void __launch_bounds__(kBlock, PT_SEARCH_OCCUPANCY)
 search_kernel(const DMesh* __restrict__ meshes, const float4* __restrict__ job_a, const float4* __restrict__ job_b,
-              const float4* __restrict__ job_c, const uint32_t* __restrict__ job_counts, float4* res, uint32_t cap,
-              uint32_t regions, uint32_t* spill, uint32_t spill_threads) {
+              const float4* __restrict__ job_c, const uint32_t* __restrict__ job_counts, SearchResults out, uint32_t cap,
+              uint32_t job_cap, uint32_t regions, uint32_t* spill, uint32_t spill_threads) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -473,16 +438,16 @@ search_kernel(const DMesh* __restrict__ meshes, const float4* __restrict__ job_a
             uint32_t n_idle = (uint32_t)__popcll(idle_mask);
             uint32_t rank = (uint32_t)__popcll(idle_mask & lane_lt);
             if (!busy && rank < avail) {
-                size_t j = (size_t)region * cap + next + rank;
+                size_t j = (size_t)region * job_cap + next + rank;
                 float4 ja = job_a[j], jb = job_b[j], jc = job_c[j];
                 ray.source = mk3(ja.x, ja.y, ja.z);
                 ray.min = ja.w;
                 ray.direction = mk3(jb.x, jb.y, jb.z);
                 ray.max = jb.w;
-                uint32_t v = __float_as_uint(jc.x), mesh_id = __float_as_uint(jc.y);
-                res_out = res + ((size_t)region * cap + v);
+                uint32_t v = __float_as_uint(jc.x), mesh_id = __float_as_uint(jc.y), m = __float_as_uint(jc.z);
+                res_out = out.res[m] + ((size_t)region * cap + v);
                 const DMesh& mesh = meshes[mesh_id];
-                // the jobs kernel has already checked the ray against the mesh bounds
+                // whoever listed the job has already checked the ray against the mesh bounds
                 ts.inv = search_inverse_direction(ray.direction);
                 ts.ray_limit = (ray.max == ray.max) ? ray.max : f32_inf();
                 ts.nodes = mesh.nodes;
@@ -707,27 +672,26 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
         b.hit_c = ws.hit_uv_y;
         return b;
     };
-    // the kernels that queue rays list the searches of the first mesh node themselves
-    FirstTarget ft;
-    memset(&ft, 0, sizeof(ft));
+    // the kernels that queue rays list the searches of those rays (every mesh node searched ahead of the walk)
+    SearchList sl;
+    memset(&sl, 0, sizeof(sl));
+    SearchResults sr;
+    for (int k = 0; k < kMaxDeferred; k++) sr.res[k] = ws.results[k];
     if (searched) {
-        ft.target = targets[0];
-        ft.job_a = ws.jobs[0];
-        ft.job_b = ws.jobs[1];
-        ft.job_c = ws.jobs[2];
-        ft.job_counts = ws.job_counts;
-        ft.res = ws.results[0];
-        ft.search_total = rt + 1;
-        ft.enabled = 1u;
+        if (!ws.jobs[0] || !ws.jobs[1] || !ws.jobs[2] || (uint64_t)cap * searched * regions > ws.job_records)
+            return hipErrorInvalidValue;
+        sl.job_a = ws.jobs[0];
+        sl.job_b = ws.jobs[1];
+        sl.job_c = ws.jobs[2];
+        sl.job_counts = ws.job_counts;
+        sl.search_total = rt + 1;
+        sl.count = searched;
+        sl.job_cap = cap * searched;
     }
-    camera_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, buffers(0), ft, cap, regions);
+    camera_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, buffers(0), sl, cap, regions);
     for (uint32_t d = 0; d < trace_depth; d++) {
         SegmentBuffers b = buffers((int)(d & 1u));
-        for (uint32_t m = 0; m < searched; m++) {
-            if (m > 0)
-                jobs_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(scene, targets[m], b.ray_a, b.ray_b, b.ray_counts,
-                                                                     ws.jobs[0], ws.jobs[1], ws.jobs[2], ws.job_counts,
-                                                                     ws.results[m], rt + 1, cap, regions);
+        if (searched) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (search_events) {
                 if ((e = hipEventCreate(&e0)) != hipSuccess) return e;
@@ -737,12 +701,12 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
                 if ((e = hipEventRecord(e0, stream)) != hipSuccess) return e;
             }
             search_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(scene.meshes, ws.jobs[0], ws.jobs[1], ws.jobs[2],
-                                                                      ws.job_counts, ws.results[m], cap, regions, ws.spill,
+                                                                      ws.job_counts, sr, cap, sl.job_cap, regions, ws.spill,
                                                                       spill_threads);
             if (search_events && (e = hipEventRecord(e1, stream)) != hipSuccess) return e;
         }
         walk_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, b, cap, regions, rt, ws.spill, spill_threads);
-        bounce_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, b, ft, cap, regions, ws.contrib);
+        bounce_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, b, sl, cap, regions, ws.contrib);
     }
     accumulate_kernel<<<blocks_for(geo.npp), kBlock, 0, stream>>>(geo, cam.width, sample_count, ws.contrib, d_accum);
     return hipGetLastError();

@@ -132,6 +132,8 @@ struct DScene {
     const DMesh* meshes;
     const DMaterial* materials;
     uint32_t mesh_count, material_count;
+    const MeshTarget* targets; // the mesh nodes in array order
+    uint32_t target_count;
 };
 
 // Camera::get_ray inputs with the per-task constants precomputed on the host.
