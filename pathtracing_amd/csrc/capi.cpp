@@ -484,6 +484,14 @@ PtStatus pt_scene_create(const PtSceneDesc* desc, int device, PtScene** out_scen
             nodes[i].mesh_ordinal = (uint32_t)s->targets.size();
             s->targets.push_back(t);
         }
+        for (uint32_t i = 0; i < desc->node_count; i++) {
+            nodes[i].only_mesh = 0xFFFFFFFFu;
+            if (nodes[i].type != PT_NODE_TRANSFORM) continue;
+            uint32_t j = i + 1;
+            while (j < desc->node_count && nodes[j].type == PT_NODE_KD_TREE) j++;
+            if (j < desc->node_count && nodes[j].type == PT_NODE_MESH && nodes[i].end == j + 1)
+                nodes[i].only_mesh = nodes[j].mesh_ordinal;
+        }
 
         // a kd_tree node directly above a mesh node offers its .tree blob to that mesh
         std::vector<const PtTreeBlob*> mesh_blob(desc->mesh_count, nullptr);

@@ -644,8 +644,11 @@ __device__ __forceinline__ Ray transform_ray_c(const __attribute__((address_spac
 }
 
 // `all_uv` = false: texture coordinates are computed only where the node's material samples a texture.
+// `live_meshes` (wave-uniform): bit m clear = no lane of the wave has a triangle in the scene's m-th
+// mesh node; a transform whose whole subtree is that mesh node is then passed over as the miss it is
+// for every lane (instances the wave's rays do not touch cost nothing).
 __device__ __forceinline__ int walk(const DScene& sc, WalkState& w, Hit& cur, bool resume, bool brute, TravStack& st,
-                                    bool all_uv = true) {
+                                    bool all_uv = true, uint32_t live_meshes = 0xFFFFFFFFu) {
     const uint32_t n = sc.node_count;
     ConstNodePtr nodes = const_nodes(sc);
     // wave-uniform cursor (see above)
@@ -691,6 +694,14 @@ __device__ __forceinline__ int walk(const DScene& sc, WalkState& w, Hit& cur, bo
             continue;
         }
         if (type == 1u) { // transform: ray.rs:21-37 with normal_matrix() of the inverse precomputed
+            const uint32_t only = nodes[i].only_mesh;
+            if (only < 32u && ((live_meshes >> only) & 1u) == 0u) {
+                cur.hit = 0u;
+                cur.hit_inside = 0u;
+                cur.t = f32_inf();
+                i = nodes[i].end;
+                continue;
+            }
             spill_store_ray(st, depth, w.ray);
             depth++;
             open = i;

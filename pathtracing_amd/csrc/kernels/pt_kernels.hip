@@ -262,11 +262,20 @@ walk_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions, un
             cur.point = mk3(0, 0, 0);
             cur.normal = mk3(0, 0, 0);
             cur.uv = mk2(0, 0);
+            // which of the searched mesh nodes hold a triangle for any ray of this wave
+            uint32_t live = 0xFFFFFFFFu;
+            if (!brute) {
+                const uint32_t searched = p.scene.target_count < (uint32_t)kMaxDeferred ? p.scene.target_count : (uint32_t)kMaxDeferred;
+                for (uint32_t m = 0; m < searched; m++) {
+                    const uint32_t found = __float_as_uint(b.res[m][base + item].y);
+                    if (__ballot(found != 0u) == 0ull) live &= ~(1u << m);
+                }
+            }
             WalkState w;
             TravState ts;
             walk_begin(w, ray);
             bool resume = false;
-            while (walk(p.scene, w, cur, resume, brute, st, false) == kWalkMesh) {
+            while (walk(p.scene, w, cur, resume, brute, st, false, live) == kWalkMesh) {
                 const uint32_t m = const_nodes(p.scene)[__builtin_amdgcn_readfirstlane(w.i)].mesh_ordinal;
                 if (m < (uint32_t)kMaxDeferred) {
                     float4 res = b.res[m][base + item];

@@ -90,7 +90,8 @@ struct DNode {
     uint32_t parent;  // nearest enclosing collection / transform node, or 0xFFFFFFFF
     uint32_t depth;   // number of enclosing collection / transform nodes
     uint32_t mesh_ordinal; // MESH: how many mesh nodes precede this one in the array
-    uint32_t pad0;
+    uint32_t only_mesh;    // TRANSFORM whose subtree is one mesh node (behind kd_tree nodes or not): that
+                           // mesh node's ordinal; 0xFFFFFFFF otherwise
     // TRANSFORM (transform.rs:33-40 plus the per-ray normal_matrix() of ray.rs:29)
     M4 matrix, matrix_inverse;
     M3 normal_matrix, inverse_normal_matrix;
