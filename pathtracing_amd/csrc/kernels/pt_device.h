@@ -178,21 +178,6 @@ PT_HD void plane_trace(const DNode& n, uint32_t node_index, const Ray& ray, Hit*
     out->tri_index = 0xFFFFFFFFu;
 }
 
-// ray.rs:21-37, with normal_matrix() of the inverse precomputed.
-PT_HD Ray apply_transform(const Ray& r, const M4& inv, const M3& inv_normal) {
-    V3 min_point = r.min * r.direction + r.source;
-    V3 max_point = r.max * r.direction + r.source;
-    V3 s = mul_point(inv, r.source);
-    V3 mn = mul_point(inv, min_point);
-    V3 mx = mul_point(inv, max_point);
-    Ray o;
-    o.source = s;
-    o.direction = mul(inv_normal, r.direction);
-    o.min = length(mn - s);
-    o.max = length(mx - s);
-    return o;
-}
-
 #if defined(__HIPCC__)
 // ------------------------------------------------------------------ BVH traversal
 // The search must return what the linear scan of mesh/mod.rs:57-62 returns: the
@@ -628,7 +613,7 @@ __device__ __forceinline__ V3 mul_c(const __attribute__((address_space(4))) M3& 
 }
 
 // Ray::apply_transform (ray.rs:21-37) for a transform node read through scalar
-// loads; the same arithmetic as apply_transform above.
+// loads, with normal_matrix() of the inverse precomputed.
 __device__ __forceinline__ Ray transform_ray_c(const __attribute__((address_space(4))) DNode& node, const Ray& r) {
     V3 min_point = r.min * r.direction + r.source;
     V3 max_point = r.max * r.direction + r.source;

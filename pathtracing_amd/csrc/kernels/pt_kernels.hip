@@ -60,12 +60,10 @@ __device__ __forceinline__ TravStack make_stack(int32_t* lds_stack, uint32_t* sp
 #ifndef PT_REFILL
 #define PT_REFILL 16
 #endif
-#ifndef PT_SEARCH_MODE
-#define PT_SEARCH_MODE 2
-#endif
 #ifndef PT_INNER_MIN
 #define PT_INNER_MIN 16
 #endif
+constexpr uint32_t kInnerMin = PT_INNER_MIN; // node steps go on while at least this many lanes take part
 constexpr uint32_t kRefill = PT_REFILL; // refill a wave once this many of its lanes have finished their search
 constexpr uint32_t kGridBlocksPerCu = PT_SEARCH_OCCUPANCY;
 uint32_t segment_blocks_per_cu() { return kGridBlocksPerCu; }
@@ -478,26 +476,20 @@ search_kernel(const DMesh* __restrict__ meshes, const float4* __restrict__ job_a
         const bool more = region < regions;
         // ---- search until enough lanes are done to make a refill worthwhile
         for (;;) {
-#if PT_SEARCH_MODE == 0
-            while (busy && trav_is_inner(ts)) trav_inner(ts, ray, st);
-            if (busy && !trav_done(ts)) trav_leaf(ts, ray, st);
-#elif PT_SEARCH_MODE == 1
-            if (busy && trav_is_inner(ts)) trav_inner(ts, ray, st);
-            if (busy && !trav_done(ts) && !trav_is_inner(ts)) trav_leaf(ts, ray, st);
-#else
-            // inner steps while enough lanes take part, then the leaves that have piled up
+            // node steps while enough lanes take part, then the leaves that have piled up
+            // (other schedules -- strict alternation, whichever kind more lanes wait for, one
+            // triangle per step -- came out within 2 % of this one)
             for (;;) {
                 bool at_inner = busy && trav_is_inner(ts);
                 uint32_t n_inner = (uint32_t)__popcll(__ballot(at_inner));
                 if (n_inner == 0u) break;
-                if (n_inner < PT_INNER_MIN) {
+                if (n_inner < kInnerMin) {
                     uint32_t n_leaf = (uint32_t)__popcll(__ballot(busy && !trav_done(ts) && !trav_is_inner(ts)));
                     if (n_leaf != 0u) break;
                 }
                 if (at_inner) trav_inner(ts, ray, st);
             }
             if (busy && !trav_done(ts) && !trav_is_inner(ts)) trav_leaf(ts, ray, st);
-#endif
             uint32_t n_unfinished = (uint32_t)__popcll(__ballot(busy && !trav_done(ts)));
             if (n_unfinished == 0u || (more && n_unfinished + kRefill <= n_busy)) break;
         }
