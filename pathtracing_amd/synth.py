@@ -14,6 +14,7 @@ large for its triangles to be visible at all but grazing angles.
 from __future__ import annotations
 
 import json
+import math
 import os
 import shutil
 
@@ -158,3 +159,46 @@ def instanced_dragon_scene_json(count: int, seed: int = 0, half: float = 40.0, s
         _plane([0.0, 0.0, -half], [0.0, 0.0, 1.0], [0.0, 1.0, 0.0], [1.0, 0.0, 0.0], "./materials/mat3.json"),
     ]
     return {"type": "node_collection", "children": children}
+
+
+def flattened_scene_json(half: float = 110.0) -> dict:
+    """One identity transform -> mesh of dragon.obj (its triangles are swapped for
+    the flattened copies after loading) between a floor, a lit ceiling and a back
+    wall `half` away: the scene graph of the flattened-instances workload."""
+    identity = [[1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]]
+    return {
+        "type": "node_collection",
+        "children": [
+            {"type": "sphere", "center": [0.0, half, half], "radius": 20.0, "material": "./materials/mat0.json"},
+            {"type": "transform", "matrix": identity,
+             "child": {"type": "mesh", "path": "./dragon.obj", "material": "./materials/mat4.json"}},
+            _plane([0.0, -half, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, -1.0], [1.0, 0.0, 0.0], "./materials/mat2.json"),
+            _plane([0.0, half, 0.0], [0.0, -1.0, 0.0], [0.0, 0.0, -1.0], [1.0, 0.0, 0.0], "./materials/mat0.json"),
+            _plane([0.0, 0.0, -half], [0.0, 0.0, 1.0], [0.0, 1.0, 0.0], [1.0, 0.0, 0.0], "./materials/mat3.json"),
+        ],
+    }
+
+
+def flattened_copies(one: np.ndarray, copies: int, seed: int = 0, spacing: float = 26.0, progress=None) -> np.ndarray:
+    """`copies` rotated (about y), scaled (1.0..1.3) and shifted copies of the
+    triangles `one` ([n, 9] float32 positions) on a jittered cubic grid centred on
+    the origin, as one array [copies * n, 9] of world-space triangles."""
+    import random
+
+    rnd = random.Random(seed)
+    side = 1
+    while side ** 3 < copies:
+        side += 1
+    n1 = one.shape[0]
+    verts = np.ascontiguousarray(one, dtype=np.float32).reshape(n1 * 3, 3)
+    out = np.empty((copies * n1, 9), dtype=np.float32)
+    for i in range(copies):
+        g = (i % side, (i // side) % side, i // (side * side))
+        shift = np.array([(g[k] - (side - 1) / 2) * spacing + rnd.uniform(-2.0, 2.0) for k in range(3)], dtype=np.float32)
+        a, sc = rnd.uniform(0.0, 2.0 * math.pi), rnd.uniform(1.0, 1.3)
+        c, s_ = math.cos(a) * sc, math.sin(a) * sc
+        rot = np.array([[c, 0.0, s_], [0.0, sc, 0.0], [-s_, 0.0, c]], dtype=np.float32)
+        out[i * n1:(i + 1) * n1] = (verts @ rot.T + shift).reshape(n1, 9)
+        if progress is not None and (i + 1) % 16 == 0:
+            progress(f"copies written: {i + 1}/{copies}")
+    return out
