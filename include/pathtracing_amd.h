@@ -304,6 +304,47 @@ PtStatus pt_tree_validate(const PtMeshDesc* mesh, const uint8_t* data, uint64_t 
 PtStatus pt_rendered_image_to_bytes(const float* rgb, uint32_t width, uint32_t height,
                                     uint8_t* out, size_t out_cap);
 
+/* RenderedImage::from_bytes (worker/src/lib.rs:64-78), what the client does with a
+ * worker's reply: width and height from the first 8 bytes, then the floats.
+ * out_rgb may be NULL to read the size only; otherwise it receives
+ * width*height*3 floats (out_cap_floats must be at least that).  A payload with
+ * fewer floats than its header announces is PT_ERR_PARSE (the reference panics);
+ * trailing bytes are ignored as Rgb32FImage::from_vec ignores them. */
+PtStatus pt_rendered_image_from_bytes(const uint8_t* bytes, size_t size, uint32_t* out_width,
+                                      uint32_t* out_height, float* out_rgb, size_t out_cap_floats);
+
+/* ------------------------------------------------- the client's frame sum */
+
+/* Frame / RenderSum (client/src/frame.rs:11-15,54-58): the element-wise sum of
+ * the renders received for one frame and their number, kept on `device`. */
+typedef struct PtFrame PtFrame;
+
+/* Frame::new (frame.rs:22-33): a zeroed width x height sum, count 0. */
+PtStatus pt_frame_create(uint32_t width, uint32_t height, int device, PtFrame** out_frame);
+void pt_frame_destroy(PtFrame* frame);
+
+/* RenderSum::add_render (frame.rs:61-71): sum += rgb (host memory, width*height*3
+ * floats in the layout pt_render returns), count += 1. */
+PtStatus pt_frame_add_render(PtFrame* frame, const float* rgb);
+
+/* The same with the render already in device memory of the frame's device (for
+ * instance pt_resolve_device's output); enqueued on `stream`, returns at once. */
+PtStatus pt_frame_add_render_device(PtFrame* frame, const float* d_rgb, void* stream);
+
+/* self.count (frame.rs:57). */
+uint64_t pt_frame_render_count(const PtFrame* frame);
+
+/* RenderSum::into_image (frame.rs:73-83) and gamma_correction (frame.rs:86-103):
+ * out_rgb (host, width*height*3 floats, may be NULL) = sum / max(count, 1);
+ * out_rgba (host, width*height*4 bytes, may be NULL) = per channel
+ * (c / (1 + c) * 255) as u8 of that mean -- truncating, saturating, NaN -> 0 as
+ * Rust's cast does -- with alpha 255.  Waits for everything queued on the device. */
+PtStatus pt_frame_image(PtFrame* frame, float* out_rgb, uint8_t* out_rgba);
+
+/* The same into device memory (either may be NULL; d_out_rgba 4-byte aligned),
+ * enqueued on `stream`. */
+PtStatus pt_frame_image_device(PtFrame* frame, float* d_out_rgb, uint8_t* d_out_rgba, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,7 +4,8 @@
 //   pt::Scene        Arc<Scene>       worker/src/scene/mod.rs:27-112  (Scene::load)
 //   pt::RenderTask   RenderTask       worker/src/api/render_task.rs:23-49
 //   pt::HipRenderer  impl Renderer    worker/src/renderer/mod.rs:9-13 (init / render)
-//   pt::RenderedImage                 worker/src/lib.rs:51-79         (to_bytes)
+//   pt::RenderedImage                 worker/src/lib.rs:51-79         (to_bytes / from_bytes)
+//   pt::Frame        Frame            client/src/frame.rs:11-103      (sum of renders, mean, RGBA8 preview)
 //   pt::Worker       Worker           worker/src/lib.rs:20-48         (scene cache + render)
 //
 // Where the reference panics (missing file, malformed JSON, ...) these throw pt::Failure.
@@ -80,6 +81,49 @@ struct RenderedImage {
         check(pt_rendered_image_to_bytes(rgb.data(), width, height, out.data(), out.size()));
         return out;
     }
+
+    static RenderedImage from_bytes(const std::vector<uint8_t>& bytes) {
+        RenderedImage img;
+        check(pt_rendered_image_from_bytes(bytes.data(), bytes.size(), &img.width, &img.height, nullptr, 0));
+        img.rgb.resize((size_t)img.width * img.height * 3);
+        check(pt_rendered_image_from_bytes(bytes.data(), bytes.size(), &img.width, &img.height, img.rgb.data(), img.rgb.size()));
+        return img;
+    }
+};
+
+// Frame (client/src/frame.rs:11-103): the running sum of the renders of one frame on one GPU,
+// its mean image and the RGBA8 preview the client shows.
+class Frame {
+public:
+    Frame(uint32_t width, uint32_t height, int device = 0) : width_(width), height_(height) {
+        check(pt_frame_create(width, height, device, &handle_));
+    }
+    Frame(const Frame&) = delete;
+    Frame& operator=(const Frame&) = delete;
+    ~Frame() { pt_frame_destroy(handle_); }
+
+    void add_render(const RenderedImage& render) {
+        if (render.width != width_ || render.height != height_) throw Failure(PT_ERR_INVALID_ARGUMENT, "render and frame differ in size");
+        check(pt_frame_add_render(handle_, render.rgb.data()));
+    }
+    uint64_t count() const { return pt_frame_render_count(handle_); }
+    RenderedImage mean_image() const {
+        RenderedImage img;
+        img.width = width_;
+        img.height = height_;
+        img.rgb.resize((size_t)width_ * height_ * 3);
+        check(pt_frame_image(handle_, img.rgb.data(), nullptr));
+        return img;
+    }
+    std::vector<uint8_t> image_rgba8() const { // gamma_correction, frame.rs:86-103
+        std::vector<uint8_t> out((size_t)width_ * height_ * 4);
+        check(pt_frame_image(handle_, nullptr, out.data()));
+        return out;
+    }
+
+private:
+    PtFrame* handle_ = nullptr;
+    uint32_t width_, height_;
 };
 
 // trait Renderer { fn init(scene: Arc<Scene>) -> Self; async fn render(&mut self, task) -> Rgb32FImage }

@@ -1293,4 +1293,33 @@ void oracle_transform_matrices(const PtMat4* m, float* inverse16, float* normal9
     }
 }
 
+// The client's frame (client/src/frame.rs): RenderSum::add_render :61-71 adds a
+// render to the running sum, into_image :73-83 divides by max(count, 1), and
+// gamma_correction :86-103 maps each channel with (c / (1 + c) * 255) as u8 —
+// Rust's float-to-u8 cast truncates toward zero, saturates at 0 and 255 and sends
+// NaN to 0 — with alpha 255.  `sum` holds pixels * 3 floats.
+void oracle_frame_add_render(float* sum, const float* render, size_t pixels) {
+    for (size_t i = 0; i < pixels * 3; i++) sum[i] = sum[i] + render[i];
+}
+
+void oracle_frame_image(const float* sum, size_t pixels, uint64_t count, float* out_rgb, uint8_t* out_rgba) {
+    const float divisor = (float)(count > 1 ? count : 1);
+    for (size_t i = 0; i < pixels; i++) {
+        for (int ch = 0; ch < 3; ch++) {
+            float c = sum[3 * i + ch] / divisor;
+            if (out_rgb) out_rgb[3 * i + ch] = c;
+            if (out_rgba) {
+                float v = c / (1.0f + c) * 255.0f;
+                uint8_t b;
+                if (v != v) b = 0;
+                else if (v <= 0.0f) b = 0;
+                else if (v >= 255.0f) b = 255;
+                else b = (uint8_t)(int)v;
+                out_rgba[4 * i + ch] = b;
+            }
+        }
+        if (out_rgba) out_rgba[4 * i + 3] = 255;
+    }
+}
+
 } // extern "C"

@@ -4,6 +4,7 @@ Python here is a thin host layer (ctypes) over ``libpathtracing_amd.so``; the
 compute path is the HIP library and nothing else.
 """
 from .api import Camera, Config, RenderOpts, RenderTask
+from .frame import Frame
 from .renderer import HIT_DTYPE, HipRenderer, Renderer, generate_rays
 from .scene import Scene
 from .worker import RenderedImage, Worker
@@ -13,6 +14,7 @@ __all__ = [
     "Config",
     "RenderOpts",
     "RenderTask",
+    "Frame",
     "HipRenderer",
     "Renderer",
     "Scene",

@@ -203,6 +203,17 @@ SYMBOLS = {
     "pt_buffer_free": (None, [C.POINTER(C.c_uint8)]),
     "pt_tree_validate": (C.c_int, [C.POINTER(PtMeshDesc), _VOIDP, C.c_uint64]),
     "pt_rendered_image_to_bytes": (C.c_int, [_VOIDP, C.c_uint32, C.c_uint32, _VOIDP, C.c_size_t]),
+    "pt_rendered_image_from_bytes": (
+        C.c_int,
+        [_VOIDP, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _VOIDP, C.c_size_t],
+    ),
+    "pt_frame_create": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_VOIDP)]),
+    "pt_frame_destroy": (None, [_VOIDP]),
+    "pt_frame_add_render": (C.c_int, [_VOIDP, _VOIDP]),
+    "pt_frame_add_render_device": (C.c_int, [_VOIDP, _VOIDP, _VOIDP]),
+    "pt_frame_render_count": (C.c_uint64, [_VOIDP]),
+    "pt_frame_image": (C.c_int, [_VOIDP, _VOIDP, _VOIDP]),
+    "pt_frame_image_device": (C.c_int, [_VOIDP, _VOIDP, _VOIDP, _VOIDP]),
 }
 
 

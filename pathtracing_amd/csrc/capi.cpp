@@ -347,6 +347,27 @@ struct DevBuf {
     DevBuf& operator=(const DevBuf&) = delete;
 };
 
+} // namespace
+
+// client/src/frame.rs:11-15,54-58: the running sum of the renders of one frame and
+// how many there were, kept on one device.
+struct PtFrame {
+    int device = 0;
+    uint32_t width = 0, height = 0;
+    uint64_t count = 0;
+    float* sum = nullptr;     // width * height * 3
+    float* staging = nullptr; // one render uploaded from the host; the mean image on its way back
+    uint8_t* rgba = nullptr;  // width * height * 4
+    size_t floats() const { return (size_t)width * height * 3; }
+    ~PtFrame() {
+        if (sum) (void)hipFree(sum);
+        if (staging) (void)hipFree(staging);
+        if (rgba) (void)hipFree(rgba);
+    }
+};
+
+namespace {
+
 void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderOpts* opts_in, float* d_accum,
                        hipStream_t stream, PtRenderStats* stats) {
     if (!scene || !task || !d_accum) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
@@ -610,6 +631,87 @@ PtStatus pt_render(PtScene* scene, const PtRenderTask* task, const PtRenderOpts*
     });
 }
 
+PtStatus pt_frame_create(uint32_t width, uint32_t height, int device, PtFrame** out_frame) {
+    return guarded([&] {
+        if (!out_frame) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        if (width == 0 || height == 0 || width > 65536 || height > 65536) throw Error(PT_ERR_INVALID_ARGUMENT, "bad image size");
+        int ndev = 0;
+        hip_check(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
+        if (device < 0 || device >= ndev) throw Error(PT_ERR_DEVICE, "no such HIP device");
+        DeviceGuard guard(device);
+        auto f = std::make_unique<PtFrame>();
+        f->device = device;
+        f->width = width;
+        f->height = height;
+        size_t bytes = f->floats() * sizeof(float);
+        hip_check(hipMalloc(reinterpret_cast<void**>(&f->sum), bytes), "hipMalloc frame");
+        hip_check(hipMalloc(reinterpret_cast<void**>(&f->staging), bytes), "hipMalloc frame");
+        hip_check(hipMalloc(reinterpret_cast<void**>(&f->rgba), (size_t)width * height * 4), "hipMalloc frame");
+        hip_check(hipMemset(f->sum, 0, bytes), "hipMemset"); // Rgb32FImage::new is zeroed, frame.rs:27
+        *out_frame = f.release();
+    });
+}
+
+void pt_frame_destroy(PtFrame* frame) {
+    if (!frame) return;
+    (void)guarded([&] {
+        DeviceGuard guard(frame->device);
+        delete frame;
+    });
+}
+
+uint64_t pt_frame_render_count(const PtFrame* frame) { return frame ? frame->count : 0; }
+
+PtStatus pt_frame_add_render(PtFrame* frame, const float* rgb) {
+    return guarded([&] {
+        if (!frame || !rgb) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        DeviceGuard guard(frame->device);
+        hip_check(hipMemcpy(frame->staging, rgb, frame->floats() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy H2D");
+        hip_check(ptk::frame_add(frame->sum, frame->staging, frame->floats(), nullptr), "frame_add");
+        hip_check(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
+        frame->count += 1;
+    });
+}
+
+PtStatus pt_frame_add_render_device(PtFrame* frame, const float* d_rgb, void* stream) {
+    return guarded([&] {
+        if (!frame || !d_rgb) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        DeviceGuard guard(frame->device);
+        hip_check(ptk::frame_add(frame->sum, d_rgb, frame->floats(), static_cast<hipStream_t>(stream)), "frame_add");
+        frame->count += 1;
+    });
+}
+
+PtStatus pt_frame_image(PtFrame* frame, float* out_rgb, uint8_t* out_rgba) {
+    return guarded([&] {
+        if (!frame) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        if (!out_rgb && !out_rgba) return;
+        DeviceGuard guard(frame->device);
+        // frame.rs:74: render_count = count.max(1), then `ch / render_count as f32`
+        float divisor = (float)std::max<uint64_t>(frame->count, 1);
+        size_t pixels = (size_t)frame->width * frame->height;
+        // the default stream waits for work other streams queued through pt_frame_add_render_device
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        hip_check(ptk::frame_image(frame->sum, pixels, divisor, out_rgb ? frame->staging : nullptr,
+                                   out_rgba ? frame->rgba : nullptr, nullptr),
+                  "frame_image");
+        if (out_rgb) hip_check(hipMemcpy(out_rgb, frame->staging, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+        if (out_rgba) hip_check(hipMemcpy(out_rgba, frame->rgba, pixels * 4, hipMemcpyDeviceToHost), "hipMemcpy D2H");
+    });
+}
+
+PtStatus pt_frame_image_device(PtFrame* frame, float* d_out_rgb, uint8_t* d_out_rgba, void* stream) {
+    return guarded([&] {
+        if (!frame) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        if (reinterpret_cast<uintptr_t>(d_out_rgba) & 3u) throw Error(PT_ERR_INVALID_ARGUMENT, "d_out_rgba is not 4-byte aligned");
+        DeviceGuard guard(frame->device);
+        float divisor = (float)std::max<uint64_t>(frame->count, 1);
+        hip_check(ptk::frame_image(frame->sum, (size_t)frame->width * frame->height, divisor, d_out_rgb, d_out_rgba,
+                                   static_cast<hipStream_t>(stream)),
+                  "frame_image");
+    });
+}
+
 PtStatus pt_trace_closest(PtScene* scene, const PtRay* rays, size_t n, uint32_t flags, PtHit* out_hits) {
     return guarded([&] {
         if (!scene || (n && (!rays || !out_hits))) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
@@ -717,6 +819,28 @@ PtStatus pt_tree_validate(const PtMeshDesc* mesh, const uint8_t* data, uint64_t 
         pt::BuiltBvh bvh;
         if (!pt::deserialize_tree(data, size, mesh->positions, mesh->triangle_count, &bvh))
             throw Error(PT_ERR_PARSE, "not a valid tree for this mesh");
+    });
+}
+
+PtStatus pt_rendered_image_from_bytes(const uint8_t* bytes, size_t size, uint32_t* out_width, uint32_t* out_height,
+                                      float* out_rgb, size_t out_cap_floats) {
+    return guarded([&] {
+        if (!bytes || !out_width || !out_height) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        if (size < 8) throw Error(PT_ERR_PARSE, "rendered image shorter than its header");
+        auto le32 = [&](size_t at) {
+            return (uint32_t)bytes[at] | ((uint32_t)bytes[at + 1] << 8) | ((uint32_t)bytes[at + 2] << 16) | ((uint32_t)bytes[at + 3] << 24);
+        };
+        uint32_t w = le32(0), h = le32(4);
+        size_t floats = (size_t)w * h * 3;
+        if ((size - 8) / 4 < floats) throw Error(PT_ERR_PARSE, "rendered image holds fewer floats than its header announces");
+        *out_width = w;
+        *out_height = h;
+        if (!out_rgb) return;
+        if (out_cap_floats < floats) throw Error(PT_ERR_INVALID_ARGUMENT, "output buffer too small");
+        for (size_t i = 0; i < floats; i++) {
+            uint32_t u = le32(8 + 4 * i);
+            memcpy(out_rgb + i, &u, 4);
+        }
     });
 }
 

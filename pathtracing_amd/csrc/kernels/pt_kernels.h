@@ -72,6 +72,13 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
 hipError_t resolve_image(const float* d_accum, uint32_t width, uint32_t height, float scale, float* d_out,
                          hipStream_t stream);
 
+// The client's frame (client/src/frame.rs:54-103) on the device: d_sum += d_render
+// over `floats` elements, and the mean image d_sum / divisor with its RGBA8
+// preview (either output may be null; d_rgba must be 4-byte aligned).
+hipError_t frame_add(float* d_sum, const float* d_render, uint64_t floats, hipStream_t stream);
+hipError_t frame_image(const float* d_sum, uint64_t pixels, float divisor, float* d_rgb, uint8_t* d_rgba,
+                       hipStream_t stream);
+
 hipError_t trace_closest(const DScene& scene, const PtRay* d_rays, size_t n, bool brute, PtHit* d_hits,
                          const Workspace& ws, hipStream_t stream);
 

@@ -537,6 +537,76 @@ __global__ void __launch_bounds__(kBlock) resolve_kernel(const float* __restrict
     dst[2] = src[2] * scale;
 }
 
+// client/src/frame.rs:61-71 (RenderSum::add_render): sum += render, element by
+// element.  kVec: both buffers are 16-byte aligned, four floats per thread.
+template <bool kVec>
+__global__ void __launch_bounds__(kBlock) frame_add_kernel(float* sum, const float* __restrict__ render,
+                                                           uint64_t floats) {
+    uint64_t i = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+    if (i >= floats) return;
+    if (kVec && i + 4 <= floats) {
+        float4 a = *reinterpret_cast<const float4*>(sum + i);
+        float4 b = *reinterpret_cast<const float4*>(render + i);
+        a.x = a.x + b.x;
+        a.y = a.y + b.y;
+        a.z = a.z + b.z;
+        a.w = a.w + b.w;
+        *reinterpret_cast<float4*>(sum + i) = a;
+        return;
+    }
+    for (uint64_t k = i; k < i + 4 && k < floats; k++) sum[k] = sum[k] + render[k];
+}
+
+// client/src/frame.rs:91-93: (c / (1 + c) * 255) as u8.  Rust's cast truncates
+// toward zero, saturates at both ends and maps NaN to 0.
+__device__ inline uint32_t tone_u8(float c) {
+    float v = c / (1.0f + c) * 255.0f;
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 255.0f) return 255u;
+    return (uint32_t)v;
+}
+
+// client/src/frame.rs:73-103 (RenderSum::into_image, gamma_correction): the mean
+// image sum / divisor and its RGBA8 preview; either output may be null.  Four
+// pixels per thread: 48 bytes in, 48 + 16 bytes out.
+template <bool kVec>
+__global__ void __launch_bounds__(kBlock) frame_image_kernel(const float* __restrict__ sum, uint64_t pixels,
+                                                             float divisor, float* out_rgb, uint32_t* out_rgba) {
+    uint64_t p0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+    if (p0 >= pixels) return;
+    float c[12];
+    const bool whole = p0 + 4 <= pixels;
+    if (kVec && whole) {
+        const float4* src = reinterpret_cast<const float4*>(sum + p0 * 3);
+        for (int k = 0; k < 3; k++) {
+            float4 v = src[k];
+            c[4 * k] = v.x;
+            c[4 * k + 1] = v.y;
+            c[4 * k + 2] = v.z;
+            c[4 * k + 3] = v.w;
+        }
+    } else {
+        for (int k = 0; k < 12; k++) c[k] = p0 * 3 + k < pixels * 3 ? sum[p0 * 3 + k] : 0.0f;
+    }
+    for (int k = 0; k < 12; k++) c[k] = c[k] / divisor;
+    uint32_t packed[4];
+    for (int q = 0; q < 4; q++)
+        packed[q] = tone_u8(c[3 * q]) | (tone_u8(c[3 * q + 1]) << 8) | (tone_u8(c[3 * q + 2]) << 16) | 0xFF000000u;
+    if (kVec && whole) {
+        if (out_rgb) {
+            float4* dst = reinterpret_cast<float4*>(out_rgb + p0 * 3);
+            for (int k = 0; k < 3; k++) dst[k] = make_float4(c[4 * k], c[4 * k + 1], c[4 * k + 2], c[4 * k + 3]);
+        }
+        if (out_rgba) *reinterpret_cast<uint4*>(out_rgba + p0) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+        return;
+    }
+    for (int q = 0; q < 4 && p0 + q < pixels; q++) {
+        if (out_rgb)
+            for (int ch = 0; ch < 3; ch++) out_rgb[(p0 + q) * 3 + ch] = c[3 * q + ch];
+        if (out_rgba) out_rgba[p0 + q] = packed[q];
+    }
+}
+
 __global__ void __launch_bounds__(kBlock, 4) trace_closest_kernel(DScene scene, const PtRay* __restrict__ rays, size_t n,
                                                                uint32_t brute, PtHit* hits, uint32_t* spill,
                                                                uint32_t spill_threads) {
@@ -718,6 +788,28 @@ hipError_t resolve_image(const float* d_accum, uint32_t width, uint32_t height, 
     uint64_t n = (uint64_t)width * height;
     if (n == 0) return hipSuccess;
     resolve_kernel<<<blocks_for(n), kBlock, 0, stream>>>(d_accum, width, height, scale, d_out);
+    return hipGetLastError();
+}
+
+static bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr) {
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15u) == 0;
+}
+
+hipError_t frame_add(float* d_sum, const float* d_render, uint64_t floats, hipStream_t stream) {
+    if (floats == 0) return hipSuccess;
+    uint32_t blocks = blocks_for((floats + 3) / 4);
+    if (aligned16(d_sum, d_render)) frame_add_kernel<true><<<blocks, kBlock, 0, stream>>>(d_sum, d_render, floats);
+    else frame_add_kernel<false><<<blocks, kBlock, 0, stream>>>(d_sum, d_render, floats);
+    return hipGetLastError();
+}
+
+hipError_t frame_image(const float* d_sum, uint64_t pixels, float divisor, float* d_rgb, uint8_t* d_rgba,
+                       hipStream_t stream) {
+    if (pixels == 0 || (!d_rgb && !d_rgba)) return hipSuccess;
+    uint32_t blocks = blocks_for((pixels + 3) / 4);
+    uint32_t* rgba = reinterpret_cast<uint32_t*>(d_rgba);
+    if (aligned16(d_sum, d_rgb, d_rgba)) frame_image_kernel<true><<<blocks, kBlock, 0, stream>>>(d_sum, pixels, divisor, d_rgb, rgba);
+    else frame_image_kernel<false><<<blocks, kBlock, 0, stream>>>(d_sum, pixels, divisor, d_rgb, rgba);
     return hipGetLastError();
 }
 

@@ -2,7 +2,7 @@
 fresh renderer per task, plus the ``RenderedImage`` wire codec (``lib.rs:51-79``)."""
 from __future__ import annotations
 
-import struct
+import ctypes as C
 from typing import Dict, Optional
 
 import numpy as np
@@ -48,6 +48,9 @@ class RenderedImage:
 
     @staticmethod
     def from_bytes(data: bytes) -> "RenderedImage":
-        w, h = struct.unpack_from("<II", data, 0)
-        img = np.frombuffer(data, dtype="<f4", offset=8, count=w * h * 3).reshape(h, w, 3)
-        return RenderedImage(img.copy())
+        raw = np.frombuffer(data, dtype=np.uint8)
+        w, h = C.c_uint32(), C.c_uint32()
+        N.check(N.lib.pt_rendered_image_from_bytes(raw.ctypes.data, raw.size, C.byref(w), C.byref(h), None, 0))
+        img = np.empty((h.value, w.value, 3), dtype=np.float32)
+        N.check(N.lib.pt_rendered_image_from_bytes(raw.ctypes.data, raw.size, C.byref(w), C.byref(h), img.ctypes.data, img.size))
+        return RenderedImage(img)

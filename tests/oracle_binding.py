@@ -56,6 +56,8 @@ class Oracle:
         lib.oracle_rng_range.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_float, C.c_float]
         lib.oracle_portable_math_array.argtypes = [C.c_int, V, V, C.c_size_t, V]
         lib.oracle_transform_matrices.argtypes = [C.POINTER(N.PtMat4), V, V, V]
+        lib.oracle_frame_add_render.argtypes = [V, V, C.c_size_t]
+        lib.oracle_frame_image.argtypes = [V, C.c_size_t, C.c_uint64, V, V]
 
     def error(self) -> str:
         return self.lib.oracle_last_error().decode()
@@ -77,6 +79,18 @@ class Oracle:
                                            rays.ctypes.data)
         assert rc == 0
         return rays
+
+    def frame(self, renders) -> tuple:
+        """client/src/frame.rs: sum of `renders` ([h, w, 3] float32 each), its mean and RGBA8 preview."""
+        h, w, _ = renders[0].shape
+        total = np.zeros((h, w, 3), dtype=np.float32)
+        for r in renders:
+            r = np.ascontiguousarray(r, dtype=np.float32)
+            self.lib.oracle_frame_add_render(total.ctypes.data, r.ctypes.data, h * w)
+        mean = np.empty((h, w, 3), dtype=np.float32)
+        rgba = np.empty((h, w, 4), dtype=np.uint8)
+        self.lib.oracle_frame_image(total.ctypes.data, h * w, len(renders), mean.ctypes.data, rgba.ctypes.data)
+        return mean, rgba
 
     def portable_math(self, fn: int, x: np.ndarray, y=None) -> np.ndarray:
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -69,3 +69,19 @@ def test_errors_are_status_codes_not_aborts():
     assert "null" in N.last_error()
     task = N.PtRenderTask()
     assert N.lib.pt_render(None, C.byref(task), None, None, None) == 1
+
+
+def test_wire_bytes_short_payloads_are_errors():
+    # RenderedImage::from_bytes, lib.rs:64-78, panics on these; here they are PT_ERR_PARSE
+    import pytest
+
+    img = np.arange(12, dtype=np.float32).reshape(2, 2, 3)
+    raw = P.RenderedImage(img).to_bytes()
+    with pytest.raises(N.PathTracingError) as e:
+        P.RenderedImage.from_bytes(raw[:7])
+    assert e.value.status == 4
+    with pytest.raises(N.PathTracingError) as e:
+        P.RenderedImage.from_bytes(raw[:-4])
+    assert e.value.status == 4
+    # trailing bytes beyond the announced floats are ignored, as Rgb32FImage::from_vec does
+    assert np.array_equal(P.RenderedImage.from_bytes(raw + b"\x00\x01\x02").image, img)
