@@ -37,6 +37,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (profiling runs)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N>1 on a box with fewer GPUs than ranks: every rank uses GPU 0, gloo instead of RCCL, the sum "
+                         "staged through host memory; checks the control flow, its numbers mean nothing")
     ap.add_argument("--scene-dir", default=os.path.join(tempfile.gettempdir(), "pathtracing_amd_dragon"))
     return ap.parse_args()
 
@@ -115,9 +118,12 @@ def main():
     if multi:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = local_rank if multi else 0
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = local_rank if multi and not args.rehearse else 0
     torch.cuda.set_device(device)
 
     # scene files: rank 0 of the node writes them, the others wait
@@ -149,7 +155,8 @@ def main():
         def render(sub, opts, buf):
             last["stats"] = renderer.render_accumulate_device(sub, opts, buf.data_ptr(), stream, want_stats=True)
 
-        render_sharded(render, frame, accum, mode="samples", seed=0)  # renders, then RCCL reduce(sum) onto rank 0
+        # renders, then RCCL reduce(sum) onto rank 0
+        render_sharded(render, frame, accum, mode="samples", seed=0, stage_on_host=args.rehearse)
         if rank == 0:
             P._native.check(P._native.lib.pt_resolve_device(accum.data_ptr(), WIDTH, HEIGHT, SPP * world, out.data_ptr(), stream))
         return last["stats"]
@@ -169,10 +176,11 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if multi:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}")
+        scalar_device = "cpu" if args.rehearse else f"cuda:{device}"
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=scalar_device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        total = torch.tensor([rays], dtype=torch.int64, device=f"cuda:{device}")
+        total = torch.tensor([rays], dtype=torch.int64, device=scalar_device)
         dist.all_reduce(total, op=dist.ReduceOp.SUM)
         rays = int(total.item())
 
@@ -219,7 +227,8 @@ def main():
             "config": {
                 "workload": f"dragon stand-in (871,200 triangles, torus-knot tube) in a textured box, {WIDTH}x{HEIGHT}, "
                             f"{SPP} samples per pixel per GPU, trace depth {DEPTH}",
-                "sharding": "sample range per GPU, RCCL reduce(sum) of the accumulation buffers onto rank 0" if multi else "single GPU",
+                "sharding": ("REHEARSAL on one GPU (gloo, host-staged sum): not a measurement" if args.rehearse else
+                             "sample range per GPU, RCCL reduce(sum) of the accumulation buffers onto rank 0") if multi else "single GPU",
                 "rays_per_step": rays // args.steps, "scene_setup_s": setup_s, "frame_mean": frame_mean,
             },
             "roofline": roofline, "cpu_baseline": ref, "cpu_baseline_bvh": bvh,

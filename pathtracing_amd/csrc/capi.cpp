@@ -2,7 +2,9 @@
 // closest-hit queries, host loaders.  Nothing here may throw across the boundary.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -68,7 +70,7 @@ struct PtScene {
     ptk::Workspace ws;
     uint64_t bvh_bytes = 0;
     uint32_t node_count = 0;
-    std::vector<ptk::MeshTarget> targets; // the scene graph's mesh nodes = BVH searches one ray needs per segment
+    std::vector<ptk::MeshTarget> targets; // the mesh nodes outside the instance run = BVH searches every ray needs per segment
     std::vector<uint32_t> mesh_tri_count;
 
     void* dev_alloc(size_t bytes) {
@@ -107,6 +109,10 @@ struct PtScene {
         ws.hit_uv_y = nullptr;
         if (ws.contrib) (void)hipFree(ws.contrib);
         ws.contrib = nullptr;
+        if (ws.run_head) (void)hipFree(ws.run_head);
+        ws.run_head = nullptr;
+        if (ws.run_res) (void)hipFree(ws.run_res);
+        ws.run_res = nullptr;
         ws.capacity_paths = 0;
         ws.contrib_paths = 0;
         ws.job_records = 0;
@@ -139,10 +145,14 @@ struct PtScene {
             for (int k = 0; k < 3; k++)
                 hip_check(hipMalloc(reinterpret_cast<void**>(&ws.queue[q][k]), records * sizeof(float4)), "hipMalloc queue");
         uint32_t result_arrays = std::min<uint32_t>((uint32_t)targets.size(), (uint32_t)ptk::kMaxDeferred);
-        ws.job_records = records * result_arrays;
-        if (result_arrays)
+        ws.job_records = records * (result_arrays + ws.run_slots);
+        if (ws.job_records)
             for (int k = 0; k < 3; k++)
                 hip_check(hipMalloc(reinterpret_cast<void**>(&ws.jobs[k]), ws.job_records * sizeof(float4)), "hipMalloc jobs");
+        if (ws.run_slots) {
+            hip_check(hipMalloc(reinterpret_cast<void**>(&ws.run_head), records * sizeof(uint32_t)), "hipMalloc run heads");
+            hip_check(hipMalloc(reinterpret_cast<void**>(&ws.run_res), ws.job_records * sizeof(float4)), "hipMalloc run results");
+        }
         for (uint32_t k = 0; k < result_arrays; k++)
             hip_check(hipMalloc(reinterpret_cast<void**>(&ws.results[k]), records * sizeof(float4)), "hipMalloc results");
         for (int k = 0; k < 2; k++)
@@ -258,6 +268,174 @@ void layout_nodes(const PtSceneDesc& d, std::vector<ptk::DNode>& out) {
         }
     }
     if (!stack.empty()) throw Error(PT_ERR_SCENE, "node array ends inside a subtree");
+}
+
+// The mesh node a transform's subtree consists of (behind kd_tree nodes or not), or 0xFFFFFFFF.
+uint32_t single_mesh_below(const std::vector<ptk::DNode>& nodes, uint32_t transform) {
+    uint32_t j = transform + 1;
+    while (j < nodes.size() && nodes[j].type == PT_NODE_KD_TREE) j++;
+    if (j < nodes.size() && nodes[j].type == PT_NODE_MESH && nodes[transform].end == j + 1) return j;
+    return 0xFFFFFFFFu;
+}
+
+// Job slots per ray set aside for the children of an instance run.  A ray of a grid of instances
+// pierces a handful of boxes; regions that run out search the rest while walking.
+constexpr uint32_t kRunSlotsPerRay = 8;
+
+struct InstanceRun {
+    uint32_t first_node = 0xFFFFFFFFu, end_node = 0xFFFFFFFFu;
+    std::vector<ptk::RunChild> children;
+};
+
+// A child's box in world space says something about a world-space ray only if the ray the child's
+// mesh sees is the image of that ray.  Ray::apply_transform (ray.rs:21-37) maps the direction with
+// the normal matrix of the inverse, i.e. with the transpose of the matrix's linear part A, and the
+// points with the inverse: the two agree on the line exactly when A^T is a multiple of A^-1, that
+// is A * A^T = lambda * I (rotation or reflection times one scale factor).  Under any other matrix
+// the reference's ray leaves the line (a quirk kept bit for bit), and the child is visited the
+// plain way.  The tolerance is far inside the widening of the boxes.
+bool keeps_lines(const ptk::M4& m) {
+    if (m.m[3][0] != 0.0f || m.m[3][1] != 0.0f || m.m[3][2] != 0.0f || m.m[3][3] != 1.0f) return false;
+    double g[3][3], lambda = 0.0;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            g[r][c] = 0.0;
+            for (int k = 0; k < 3; k++) g[r][c] += (double)m.m[r][k] * (double)m.m[c][k];
+        }
+    for (int r = 0; r < 3; r++) lambda += g[r][r] / 3.0;
+    if (!(lambda > 1e-30) || !std::isfinite(lambda)) return false;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++)
+            if (!(std::fabs(g[r][c] - (r == c ? lambda : 0.0)) <= 1e-5 * lambda)) return false;
+    for (int r = 0; r < 3; r++)
+        if (!std::isfinite(m.m[r][3])) return false;
+    return true;
+}
+
+// The longest run of consecutive children of the root collection that are transform -> (kd_tree ->)
+// mesh subtrees, if it has at least PATHTRACING_AMD_INSTANCE_RUN_MIN children (default 4; 0 = never).
+InstanceRun find_instance_run(const std::vector<ptk::DNode>& nodes) {
+    InstanceRun best;
+    uint32_t min_children = 4;
+    if (const char* v = getenv("PATHTRACING_AMD_INSTANCE_RUN_MIN")) min_children = (uint32_t)strtoul(v, nullptr, 10);
+    if (min_children == 0 || nodes.empty() || nodes[0].type != PT_NODE_COLLECTION) return best;
+    InstanceRun cur;
+    auto close = [&] {
+        if (cur.children.size() >= min_children && cur.children.size() > best.children.size()) best = cur;
+        cur = InstanceRun();
+    };
+    for (uint32_t c = 1; c < nodes[0].end; c = nodes[c].end) {
+        uint32_t mesh_node = (nodes[c].type == PT_NODE_TRANSFORM && keeps_lines(nodes[c].matrix)) ? single_mesh_below(nodes, c) : 0xFFFFFFFFu;
+        if (mesh_node == 0xFFFFFFFFu) {
+            close();
+            continue;
+        }
+        if (cur.children.empty()) cur.first_node = c;
+        cur.end_node = nodes[c].end;
+        cur.children.push_back(ptk::RunChild{c, mesh_node, nodes[mesh_node].mesh_id, 0u});
+    }
+    close();
+    return best;
+}
+
+// Bounding-volume tree over the world-space boxes of the run's children, in depth-first order
+// with skip links.  A child's box is the box of the eight corners of its mesh's (padded) bounds
+// under the child's matrix, computed in double, then widened by 1e-4 of its size and position:
+// far more than the f32 rounding of the ray's way into the mesh's space and back, so a ray that
+// can hit a triangle of the child pierces the box.
+std::vector<ptk::TlasNode> build_run_tree(const InstanceRun& run, const std::vector<ptk::DNode>& nodes,
+                                          const std::vector<ptk::DMesh>& meshes) {
+    struct Box {
+        double lo[3], hi[3];
+    };
+    const size_t n = run.children.size();
+    std::vector<Box> boxes(n);
+    for (size_t k = 0; k < n; k++) {
+        const ptk::DMesh& mesh = meshes[run.children[k].mesh_id];
+        const ptk::M4& m = nodes[run.children[k].transform_node].matrix;
+        Box b;
+        for (int a = 0; a < 3; a++) b.lo[a] = INFINITY, b.hi[a] = -INFINITY;
+        for (int corner = 0; corner < 8; corner++) {
+            double p[3] = {corner & 1 ? mesh.bmax[0] : mesh.bmin[0], corner & 2 ? mesh.bmax[1] : mesh.bmin[1],
+                           corner & 4 ? mesh.bmax[2] : mesh.bmin[2]};
+            double w = m.m[3][0] * p[0] + m.m[3][1] * p[1] + m.m[3][2] * p[2] + m.m[3][3];
+            for (int a = 0; a < 3; a++) {
+                double v = (m.m[a][0] * p[0] + m.m[a][1] * p[1] + m.m[a][2] * p[2] + m.m[a][3]) / w;
+                if (!(v == v)) v = INFINITY; // degenerate matrix: the box below becomes unbounded
+                b.lo[a] = std::min(b.lo[a], v);
+                b.hi[a] = std::max(b.hi[a], v);
+            }
+        }
+        bool bounded = true;
+        for (int a = 0; a < 3; a++) bounded = bounded && std::isfinite(b.lo[a]) && std::isfinite(b.hi[a]);
+        for (int a = 0; a < 3; a++) {
+            if (!bounded || mesh.tri_count == 0) { // an unbounded box is always pierced: the exact test in the child's space decides
+                b.lo[a] = -INFINITY;
+                b.hi[a] = INFINITY;
+                continue;
+            }
+            double pad = 1e-4 * ((b.hi[a] - b.lo[a]) + std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a]))) + 1e-6;
+            b.lo[a] -= pad;
+            b.hi[a] += pad;
+        }
+        boxes[k] = b;
+    }
+    std::vector<ptk::TlasNode> out;
+    out.reserve(2 * n);
+    auto down = [](double v) { return std::nextafterf((float)v, -INFINITY); };
+    auto up = [](double v) { return std::nextafterf((float)v, INFINITY); };
+    // children are put into the tree in any order: the run's result does not depend on the order of visit
+    std::vector<uint32_t> order(n);
+    for (size_t k = 0; k < n; k++) order[k] = (uint32_t)k;
+    struct Builder {
+        std::vector<ptk::TlasNode>& out;
+        std::vector<Box>& boxes;
+        std::vector<uint32_t>& order;
+        decltype(down)& dn;
+        decltype(up)& upf;
+        Box build(size_t lo, size_t hi) {
+            size_t at = out.size();
+            out.push_back(ptk::TlasNode{});
+            Box b;
+            if (hi - lo == 1) {
+                b = boxes[order[lo]];
+                out[at].child = order[lo];
+            } else {
+                double cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+                auto centre = [&](uint32_t k, int a) {
+                    double c = 0.5 * (boxes[k].lo[a] + boxes[k].hi[a]);
+                    return std::isfinite(c) ? c : 0.0;
+                };
+                for (size_t i = lo; i < hi; i++)
+                    for (int a = 0; a < 3; a++) {
+                        cmin[a] = std::min(cmin[a], centre(order[i], a));
+                        cmax[a] = std::max(cmax[a], centre(order[i], a));
+                    }
+                int axis = 0;
+                for (int a = 1; a < 3; a++)
+                    if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
+                size_t mid = lo + (hi - lo) / 2;
+                std::nth_element(order.begin() + lo, order.begin() + mid, order.begin() + hi,
+                                 [&](uint32_t x, uint32_t y) { return centre(x, axis) < centre(y, axis); });
+                Box l = build(lo, mid), r = build(mid, hi);
+                for (int a = 0; a < 3; a++) {
+                    b.lo[a] = std::min(l.lo[a], r.lo[a]);
+                    b.hi[a] = std::max(l.hi[a], r.hi[a]);
+                }
+                out[at].child = ptk::kTlasInner;
+            }
+            for (int a = 0; a < 3; a++) {
+                out[at].bmin[a] = dn(b.lo[a]);
+                out[at].bmax[a] = upf(b.hi[a]);
+            }
+            out[at].skip = (uint32_t)out.size();
+            return b;
+        }
+    } builder{out, boxes, order, down, up};
+    builder.build(0, n);
+    for (size_t i = 0; i < out.size(); i++)
+        if (out[i].skip <= i) throw Error(PT_ERR_SCENE, "instance tree: skip link does not advance");
+    return out;
 }
 
 void build_mesh(PtScene& s, const PtMeshDesc& m, const PtTreeBlob* blob, ptk::DMesh* out) {
@@ -491,8 +669,13 @@ PtStatus pt_scene_create(const PtSceneDesc* desc, int device, PtScene** out_scen
         std::vector<ptk::DNode> nodes;
         layout_nodes(*desc, nodes);
         s->node_count = desc->node_count;
+        InstanceRun run = find_instance_run(nodes);
         for (uint32_t i = 0; i < desc->node_count; i++) {
             if (nodes[i].type != PT_NODE_MESH) continue;
+            if (i >= run.first_node && i < run.end_node) {
+                nodes[i].mesh_ordinal = 0xFFFFFFFFu; // reached through the run, never by the walk itself
+                continue;
+            }
             ptk::MeshTarget t{};
             t.node_index = i;
             t.mesh_id = nodes[i].mesh_id;
@@ -508,10 +691,8 @@ PtStatus pt_scene_create(const PtSceneDesc* desc, int device, PtScene** out_scen
         for (uint32_t i = 0; i < desc->node_count; i++) {
             nodes[i].only_mesh = 0xFFFFFFFFu;
             if (nodes[i].type != PT_NODE_TRANSFORM) continue;
-            uint32_t j = i + 1;
-            while (j < desc->node_count && nodes[j].type == PT_NODE_KD_TREE) j++;
-            if (j < desc->node_count && nodes[j].type == PT_NODE_MESH && nodes[i].end == j + 1)
-                nodes[i].only_mesh = nodes[j].mesh_ordinal;
+            uint32_t j = single_mesh_below(nodes, i);
+            if (j != 0xFFFFFFFFu) nodes[i].only_mesh = nodes[j].mesh_ordinal;
         }
 
         // a kd_tree node directly above a mesh node offers its .tree blob to that mesh
@@ -575,6 +756,17 @@ PtStatus pt_scene_create(const PtSceneDesc* desc, int device, PtScene** out_scen
         s->d.material_count = desc->material_count;
         s->d.targets = s->upload(s->targets);
         s->d.target_count = (uint32_t)s->targets.size();
+        memset(&s->d.run, 0, sizeof(s->d.run));
+        if (!run.children.empty()) {
+            std::vector<ptk::TlasNode> tlas = build_run_tree(run, nodes, meshes);
+            s->d.run.tlas = s->upload(tlas);
+            s->d.run.children = s->upload(run.children);
+            s->d.run.tlas_count = (uint32_t)tlas.size();
+            s->d.run.child_count = (uint32_t)run.children.size();
+            s->d.run.first_node = run.first_node;
+            s->d.run.end_node = run.end_node;
+            s->ws.run_slots = std::min<uint32_t>((uint32_t)run.children.size(), kRunSlotsPerRay);
+        }
         hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
         *out_scene = s.release();
     });

@@ -628,12 +628,153 @@ __device__ __forceinline__ Ray transform_ray_c(const __attribute__((address_spac
     return o;
 }
 
+// Ray::apply_transform (ray.rs:21-37) with the node read by this lane alone: inside an
+// instance run the lanes of a wave are at different children.
+__device__ __forceinline__ Ray transform_ray_g(const DNode& node, const Ray& r) {
+    V3 min_point = r.min * r.direction + r.source;
+    V3 max_point = r.max * r.direction + r.source;
+    V3 s = mul_point(node.matrix_inverse, r.source);
+    V3 mn = mul_point(node.matrix_inverse, min_point);
+    V3 mx = mul_point(node.matrix_inverse, max_point);
+    Ray o;
+    o.source = s;
+    o.direction = mul(node.inverse_normal_matrix, r.direction);
+    o.min = length(mn - s);
+    o.max = length(mx - s);
+    return o;
+}
+
+// ---- instance run (DRun) -----------------------------------------------------
+// Cursor over the children of the run whose world-space box the ray pierces.
+struct RunCursor {
+    V3 inv;
+    float limit;
+    uint32_t i; // next node of the box tree to look at
+};
+__device__ __forceinline__ void run_begin(const DRun& run, const Ray& world, bool active, RunCursor& c) {
+    c.inv = mk3(1.0f / world.direction.x, 1.0f / world.direction.y, 1.0f / world.direction.z);
+    // The whole half-line: a child tests t against the ray's range in its own space, where a
+    // scaled child measures min and max as distances but t along a direction that is not of unit
+    // length (ray.rs:21-37), so hits beyond the world-space max can be accepted.
+    c.limit = f32_inf();
+    // rays with a non-finite component hit no triangle (trav_reaches)
+    c.i = (active && all_finite(world.source) && all_finite(world.direction)) ? 0u : run.tlas_count;
+}
+// The next such child (index in child order, any order of visit), or kRunNone.
+// Ends: `skip` of a node is larger than the node's own index.
+__device__ __forceinline__ uint32_t run_next(const DRun& run, const Ray& world, RunCursor& c) {
+    GlobalF4Ptr nodes = global_f4(run.tlas);
+    while (c.i < run.tlas_count) {
+        float4 a = nodes[2 * (int)c.i], b = nodes[2 * (int)c.i + 1];
+        float bmin[3] = {a.x, a.y, a.z}, bmax[3] = {b.x, b.y, b.z};
+        const uint32_t skip = __float_as_uint(a.w), child = __float_as_uint(b.w);
+        float entry;
+        const bool pierced = box_test(bmin, bmax, world.source, c.inv, c.limit, &entry);
+        if (pierced && child != kTlasInner) {
+            c.i = skip;
+            return child;
+        }
+        c.i = pierced ? c.i + 1u : skip;
+    }
+    return kRunNone;
+}
+
+// What the run's child k returns for `world` (transform.rs:45-66 around
+// hierarchy/mesh.rs:61-66), given the closest triangle of its mesh for the ray in
+// the mesh's space.
+__device__ __forceinline__ void run_child_hit(const DScene& sc, uint32_t k, const Ray& world, float t, uint32_t slot,
+                                              uint32_t orig, Hit* h) {
+    const RunChild rc = sc.run.children[k];
+    const DNode& tn = sc.nodes[rc.transform_node];
+    Ray local = transform_ray_g(tn, world);
+    const DMesh& mesh = sc.meshes[rc.mesh_id];
+    DNode nd;
+    nd.material_id = sc.nodes[rc.mesh_node].material_id;
+    nd.mesh_id = rc.mesh_id;
+    mesh_result(mesh, nd, rc.mesh_node, local, true, t, mesh.tris + slot, orig, h);
+    if (h->hit) {
+        V3 point = mul_point(tn.matrix, h->point);
+        h->t = length(point - world.source);
+        h->point = point;
+        h->normal = mul(tn.normal_matrix, h->normal);
+    }
+}
+
+// node_collection.rs:48-52 over the children of the run: `h` of child k replaces the
+// running best when it is closer, or as close and from an earlier child (the
+// sequential loop keeps the first of equals; the candidates arrive in any order).
+__device__ __forceinline__ void run_take(Hit& best, uint32_t& best_k, const Hit& h, uint32_t k) {
+    if (h.hit && (h.t < best.t || (best.hit && h.t == best.t && k < best_k))) {
+        best = h;
+        best_k = k;
+    }
+}
+
+// Where a lane finds the searches that were run ahead for its ray within the run.
+struct RunLookup {
+    uint32_t head;         // the ray's last job (index within the region), kRunNone, or kRunInPlace
+    const float4* job_c;   // the region's jobs: (.., .., flag | child, previous job of the ray)
+    const float4* run_res; // the region's results per job: (t, found, leaf slot, triangle index)
+};
+
+__device__ __forceinline__ void search_in_place(const DMesh& mesh, const Ray& ray, TravStack& st, TravState& ts);
+
+// The run's result for `world`: min over its children as the reference's loop
+// would find it.  With `look` the searches were run ahead; without (or when the
+// job list was full) every candidate child is searched here.
+__device__ __forceinline__ void walk_run(const DScene& sc, const Ray& world, const RunLookup* look, TravStack& st, Hit* out) {
+    Hit best;
+    best.hit = 0u;
+    best.hit_inside = 0u;
+    best.t = f32_inf();
+    best.material_id = 0u;
+    best.node_index = 0xFFFFFFFFu;
+    best.tri_index = 0xFFFFFFFFu;
+    best.point = mk3(0, 0, 0);
+    best.normal = mk3(0, 0, 0);
+    best.uv = mk2(0, 0);
+    uint32_t best_k = 0xFFFFFFFFu;
+    if (look != nullptr && look->head != kRunInPlace) {
+        GlobalF4Ptr jobs = global_f4(look->job_c), results = global_f4(look->run_res);
+        uint32_t j = look->head;
+        while (j != kRunNone) {
+            const float4 jc = jobs[(int)j], res = results[(int)j];
+            if (__float_as_uint(res.y) != 0u) {
+                const uint32_t k = __float_as_uint(jc.z) & ~kRunJobFlag;
+                Hit h;
+                run_child_hit(sc, k, world, res.x, __float_as_uint(res.z), __float_as_uint(res.w), &h);
+                run_take(best, best_k, h, k);
+            }
+            j = __float_as_uint(jc.w);
+        }
+    } else {
+        RunCursor c;
+        run_begin(sc.run, world, true, c);
+        for (uint32_t k = run_next(sc.run, world, c); k != kRunNone; k = run_next(sc.run, world, c)) {
+            const RunChild rc = sc.run.children[k];
+            Ray local = transform_ray_g(sc.nodes[rc.transform_node], world);
+            TravState ts;
+            search_in_place(sc.meshes[rc.mesh_id], local, st, ts);
+            if (ts.found != 0u) {
+                Hit h;
+                run_child_hit(sc, k, world, ts.tbest, ts.best_slot, ts.best_orig, &h);
+                run_take(best, best_k, h, k);
+            }
+        }
+    }
+    *out = best;
+}
+
 // `all_uv` = false: texture coordinates are computed only where the node's material samples a texture.
 // `live_meshes` (wave-uniform): bit m clear = no lane of the wave has a triangle in the scene's m-th
 // mesh node; a transform whose whole subtree is that mesh node is then passed over as the miss it is
 // for every lane (instances the wave's rays do not touch cost nothing).
+// kRun: the scene's instance run (if any) is taken as a whole; `run`: the searches run ahead for
+// this lane's ray inside it (null: none were).  Without kRun the run's children are walked like
+// any other node (kernels for scenes without a run carry none of its code).
+template <bool kRun = true>
 __device__ __forceinline__ int walk(const DScene& sc, WalkState& w, Hit& cur, bool resume, bool brute, TravStack& st,
-                                    bool all_uv = true, uint32_t live_meshes = 0xFFFFFFFFu) {
+                                    bool all_uv = true, uint32_t live_meshes = 0xFFFFFFFFu, const RunLookup* run = nullptr) {
     const uint32_t n = sc.node_count;
     ConstNodePtr nodes = const_nodes(sc);
     // wave-uniform cursor (see above)
@@ -666,6 +807,13 @@ __device__ __forceinline__ int walk(const DScene& sc, WalkState& w, Hit& cur, bo
             if (open_is_collection && cur.hit && cur.t < w.best.t) w.best = cur;
         }
         if (i >= n) break;
+        if (kRun && !brute && sc.run.child_count != 0u && i == sc.run.first_node) {
+            // the instance run: all its children at once (the linear-scan mode visits them one by one below)
+            walk_run(sc, w.ray, run, st, &cur);
+            i = sc.run.end_node;
+            if (open_is_collection && cur.hit && cur.t < w.best.t) w.best = cur;
+            continue;
+        }
         uint32_t type = nodes[i].type;
         if (type == 0u) { // collection
             if (depth > 0) spill_store_hit(st, depth, w.best);

@@ -30,6 +30,11 @@ struct Workspace {
     uint32_t* job_counts = nullptr;
     uint64_t job_records = 0;
     float4* results[16] = {};
+    // instance run: job slots per ray set aside for its children, per ray the head of its chain of
+    // jobs (indexed like a queue), per job its result (indexed like `jobs`)
+    uint32_t run_slots = 0;
+    uint32_t* run_head = nullptr;
+    float4* run_res = nullptr;
     // the segment's hit per ray, indexed like a queue: (point, material | inside << 31) (normal, uv.x), uv.y
     float4* hits[2] = {nullptr, nullptr};
     float* hit_uv_y = nullptr;

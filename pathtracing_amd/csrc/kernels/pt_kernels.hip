@@ -83,6 +83,11 @@ struct SegmentBuffers {
     float4* res[kMaxDeferred];
     float4 *hit_a, *hit_b; // the segment's hits, written by walk_kernel for bounce_kernel
     float* hit_c;
+    // instance run: per ray the head of its chain of jobs, the job rows that hold the chain, one result per job
+    uint32_t* run_head;
+    const float4* run_job_c;
+    float4* run_res;
+    uint32_t job_cap; // job records per region
 };
 
 // Where the kernels that queue rays list the BVH searches of those rays: one job per
@@ -93,8 +98,11 @@ struct SearchList {
     float4 *job_a, *job_b, *job_c;
     uint32_t* job_counts;
     unsigned long long* search_total;
-    uint32_t count;   // mesh nodes listed: the scene's first `count` (0: nothing is searched ahead of the walk)
+    uint32_t count;   // mesh nodes listed: the scene's first `count` outside the instance run
+    uint32_t run;     // 1: the children of the instance run are listed too
+    uint32_t run_cap; // how many of a region's job records the run's children may take
     uint32_t job_cap; // job records per region
+    uint32_t* run_head; // per ray (indexed like the queue): head of its chain of run jobs
 };
 
 typedef const __attribute__((address_space(4))) MeshTarget* ConstTargetPtr;
@@ -105,9 +113,10 @@ typedef const __attribute__((address_space(4))) MeshTarget* ConstTargetPtr;
 // transform.rs:45-48); if it can reach the mesh it becomes a job, otherwise its "no
 // triangle" result is stored right here.  Wave-uniform control flow; `job_pos`
 // counts the region's jobs.
+template <bool kRun>
 __device__ __forceinline__ void list_searches(const DScene& scene, const SearchList& sl, float4* const* res, bool queued,
                                               const Ray& world, uint32_t r, uint32_t cap, uint32_t item, uint32_t& job_pos,
-                                              unsigned long long lane_lt) {
+                                              uint32_t& run_used, unsigned long long lane_lt) {
     ConstNodePtr nodes = const_nodes(scene);
     ConstTargetPtr targets = (ConstTargetPtr)(unsigned long long)scene.targets;
     const size_t job_base = (size_t)r * sl.job_cap;
@@ -132,6 +141,47 @@ __device__ __forceinline__ void list_searches(const DScene& scene, const SearchL
         }
         job_pos += (uint32_t)__popcll(mask);
     }
+    if (!kRun || sl.run == 0u) return;
+    // The instance run: one job per child whose world-space box the ray pierces and whose mesh
+    // bounds the ray reaches in the child's space.  A ray's jobs are chained through job_c.w.
+    // When the region's job list is full the ray is marked and searched while walking instead.
+    RunCursor cursor;
+    run_begin(scene.run, world, queued, cursor);
+    uint32_t head = kRunNone;
+    for (;;) {
+        const uint32_t k = run_next(scene.run, world, cursor);
+        if (__ballot(k != kRunNone) == 0ull) break;
+        bool need = false;
+        Ray ray = world;
+        uint32_t mesh_id = 0u;
+        if (k != kRunNone) {
+            const RunChild rc = scene.run.children[k];
+            mesh_id = rc.mesh_id;
+            ray = transform_ray_g(scene.nodes[rc.transform_node], world);
+            need = trav_reaches(scene.meshes[mesh_id], ray);
+        }
+        const unsigned long long mask = __ballot(need);
+        const uint32_t wanted = (uint32_t)__popcll(mask);
+        if (run_used + wanted > sl.run_cap) { // wave-uniform; the other mesh nodes' share of the list stays theirs
+            if (need) {
+                head = kRunInPlace;
+                cursor.i = scene.run.tlas_count;
+            }
+            continue;
+        }
+        if (need) {
+            const uint32_t at = job_pos + (uint32_t)__popcll(mask & lane_lt);
+            const size_t j = job_base + at;
+            sl.job_a[j] = make_float4(ray.source.x, ray.source.y, ray.source.z, ray.min);
+            sl.job_b[j] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, ray.max);
+            sl.job_c[j] = make_float4(__uint_as_float(item), __uint_as_float(mesh_id), __uint_as_float(kRunJobFlag | k),
+                                      __uint_as_float(head));
+            head = at;
+        }
+        job_pos += wanted;
+        run_used += wanted;
+    }
+    if (queued) sl.run_head[(size_t)r * cap + item] = head;
 }
 
 // -------------------------------------------------------------- camera kernel
@@ -153,6 +203,7 @@ __host__ __device__ inline uint32_t camera_xcd_classes(uint32_t regions, uint32_
     return (regions % (8u * kWavesPerBlock) == 0u && nby >= 32u) ? 8u : 1u;
 }
 
+template <bool kRun>
 __global__ void __launch_bounds__(kBlock)
 camera_kernel(RenderParams p, SegmentBuffers b, SearchList sl, uint32_t cap, uint32_t regions) {
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
@@ -166,7 +217,7 @@ camera_kernel(RenderParams p, SegmentBuffers b, SearchList sl, uint32_t cap, uin
     unsigned long long listed = 0;
     for (uint32_t r = wave; r < regions; r += waves) {
         const size_t base = (size_t)r * cap;
-        uint32_t out_pos = 0u, job_pos = 0u;
+        uint32_t out_pos = 0u, job_pos = 0u, run_used = 0u;
         // region r belongs to workgroup r / 4, whose XCD class is (r / 4) mod 8
         const uint32_t xcd = (r / kWavesPerBlock) % xcds;
         const uint32_t index_in_xcd = (r / (kWavesPerBlock * xcds)) * kWavesPerBlock + (r % kWavesPerBlock);
@@ -200,12 +251,12 @@ camera_kernel(RenderParams p, SegmentBuffers b, SearchList sl, uint32_t cap, uin
                 b.ray_b[o] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, __uint_as_float((uint32_t)slot));
                 b.ray_c[o] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng_counter));
             }
-            if (sl.count) list_searches(p.scene, sl, b.res, have, ray, r, cap, item, job_pos, lane_lt);
+            if (sl.count | sl.run) list_searches<kRun>(p.scene, sl, b.res, have, ray, r, cap, item, job_pos, run_used, lane_lt);
             out_pos += (uint32_t)__popcll(mask);
         }
         if (lane == 0u) {
             b.ray_counts[r] = out_pos;
-            if (sl.count) sl.job_counts[r] = job_pos;
+            if (sl.count | sl.run) sl.job_counts[r] = job_pos;
         }
         listed += job_pos;
     }
@@ -225,6 +276,7 @@ camera_kernel(RenderParams p, SegmentBuffers b, SearchList sl, uint32_t cap, uin
 #ifndef PT_WALK_OCCUPANCY
 #define PT_WALK_OCCUPANCY 3
 #endif
+template <bool kRun>
 __global__ void __launch_bounds__(kBlock, PT_WALK_OCCUPANCY)
 walk_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions, unsigned long long* ray_total,
             uint32_t* spill, uint32_t spill_threads) {
@@ -269,11 +321,19 @@ walk_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions, un
                     if (__ballot(found != 0u) == 0ull) live &= ~(1u << m);
                 }
             }
+            // the searches run ahead inside the instance run, if the scene has one
+            RunLookup look;
+            const bool have_run = kRun && !brute && p.scene.run.child_count != 0u;
+            if (have_run) {
+                look.head = b.run_head[base + item];
+                look.job_c = b.run_job_c + (size_t)r * b.job_cap;
+                look.run_res = b.run_res + (size_t)r * b.job_cap;
+            }
             WalkState w;
             TravState ts;
             walk_begin(w, ray);
             bool resume = false;
-            while (walk(p.scene, w, cur, resume, brute, st, false, live) == kWalkMesh) {
+            while (walk<kRun>(p.scene, w, cur, resume, brute, st, false, live, have_run ? &look : nullptr) == kWalkMesh) {
                 const uint32_t m = const_nodes(p.scene)[__builtin_amdgcn_readfirstlane(w.i)].mesh_ordinal;
                 if (m < (uint32_t)kMaxDeferred) {
                     float4 res = b.res[m][base + item];
@@ -304,6 +364,7 @@ walk_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions, un
 #ifndef PT_BOUNCE_OCCUPANCY
 #define PT_BOUNCE_OCCUPANCY 4
 #endif
+template <bool kRun>
 __global__ void __launch_bounds__(kBlock, PT_BOUNCE_OCCUPANCY)
 bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList sl, uint32_t cap, uint32_t regions,
               float* contrib) {
@@ -317,7 +378,7 @@ bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList sl, u
     for (uint32_t r = wave; r < regions; r += waves) {
         const size_t base = (size_t)r * cap;
         const uint32_t n_items = b.ray_counts[r];
-        uint32_t out_pos = 0u, job_pos = 0u;
+        uint32_t out_pos = 0u, job_pos = 0u, run_used = 0u;
         for (uint32_t first = 0; first < n_items; first += 64u) {
             const uint32_t item = first + lane;
             bool emit = false;
@@ -383,12 +444,13 @@ bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList sl, u
                 b.next_b[slot] = make_float4(nray.direction.x, nray.direction.y, nray.direction.z, __uint_as_float(path));
                 b.next_c[slot] = make_float4(nmult.x, nmult.y, nmult.z, __uint_as_float(rng_counter));
             }
-            if (sl.count && emit_mask != 0ull) list_searches(p.scene, sl, b.res, emit, nray, r, cap, next_item, job_pos, lane_lt);
+            if ((sl.count | sl.run) && emit_mask != 0ull)
+                list_searches<kRun>(p.scene, sl, b.res, emit, nray, r, cap, next_item, job_pos, run_used, lane_lt);
             out_pos += (uint32_t)__popcll(emit_mask);
         }
         if (lane == 0u) {
             b.next_counts[r] = out_pos;
-            if (sl.count) sl.job_counts[r] = job_pos;
+            if (sl.count | sl.run) sl.job_counts[r] = job_pos;
         }
         listed += job_pos;
     }
@@ -398,6 +460,7 @@ bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList sl, u
 // -------------------------------------------------------------- search kernel
 struct SearchResults {
     float4* res[kMaxDeferred]; // per listed mesh node: closest triangle per ray, indexed like the ray queue
+    float4* run_res;           // jobs of the instance run: closest triangle per job, indexed like the job list
 };
 
 // The BVH searches listed by the kernels that queued the rays (list_searches), for
@@ -452,7 +515,7 @@ search_kernel(const DMesh* __restrict__ meshes, const float4* __restrict__ job_a
                 ray.direction = mk3(jb.x, jb.y, jb.z);
                 ray.max = jb.w;
                 uint32_t v = __float_as_uint(jc.x), mesh_id = __float_as_uint(jc.y), m = __float_as_uint(jc.z);
-                res_out = out.res[m] + ((size_t)region * cap + v);
+                res_out = (m & kRunJobFlag) ? out.run_res + j : out.res[m] + ((size_t)region * cap + v);
                 const DMesh& mesh = meshes[mesh_id];
                 // whoever listed the job has already checked the ray against the mesh bounds
                 ts.inv = search_inverse_direction(ray.direction);
@@ -723,6 +786,9 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
     const uint32_t searched = brute ? 0u : std::min<uint32_t>((uint32_t)targets.size(), (uint32_t)kMaxDeferred);
     for (uint32_t m = 0; m < searched; m++)
         if (!ws.results[m]) return hipErrorInvalidValue;
+    // job slots per ray for the children of the instance run (more candidates than that are searched while walking)
+    const uint32_t run_slots = (!brute && scene.run.child_count != 0u) ? ws.run_slots : 0u;
+    if (run_slots && (!ws.run_head || !ws.run_res)) return hipErrorInvalidValue;
     const uint32_t spill_threads = ws.persistent_blocks * kBlock;
     unsigned long long* rt = reinterpret_cast<unsigned long long*>(ws.ray_total);
     hipError_t e;
@@ -741,6 +807,10 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
         b.hit_a = ws.hits[0];
         b.hit_b = ws.hits[1];
         b.hit_c = ws.hit_uv_y;
+        b.run_head = ws.run_head;
+        b.run_job_c = ws.jobs[2];
+        b.run_res = ws.run_res;
+        b.job_cap = cap * (searched + run_slots);
         return b;
     };
     // the kernels that queue rays list the searches of those rays (every mesh node searched ahead of the walk)
@@ -748,8 +818,9 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
     memset(&sl, 0, sizeof(sl));
     SearchResults sr;
     for (int k = 0; k < kMaxDeferred; k++) sr.res[k] = ws.results[k];
-    if (searched) {
-        if (!ws.jobs[0] || !ws.jobs[1] || !ws.jobs[2] || (uint64_t)cap * searched * regions > ws.job_records)
+    sr.run_res = ws.run_res;
+    if (searched || run_slots) {
+        if (!ws.jobs[0] || !ws.jobs[1] || !ws.jobs[2] || (uint64_t)cap * (searched + run_slots) * regions > ws.job_records)
             return hipErrorInvalidValue;
         sl.job_a = ws.jobs[0];
         sl.job_b = ws.jobs[1];
@@ -757,12 +828,18 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
         sl.job_counts = ws.job_counts;
         sl.search_total = rt + 1;
         sl.count = searched;
-        sl.job_cap = cap * searched;
+        sl.run = run_slots ? 1u : 0u;
+        sl.run_cap = cap * run_slots;
+        sl.job_cap = cap * (searched + run_slots);
+        sl.run_head = ws.run_head;
     }
-    camera_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, buffers(0), sl, cap, regions);
+    // scenes with an instance run get the kernels that know about it; the others carry none of its code
+    const bool with_run = run_slots != 0u;
+    if (with_run) camera_kernel<true><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, buffers(0), sl, cap, regions);
+    else camera_kernel<false><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, buffers(0), sl, cap, regions);
     for (uint32_t d = 0; d < trace_depth; d++) {
         SegmentBuffers b = buffers((int)(d & 1u));
-        if (searched) {
+        if (searched || run_slots) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (search_events) {
                 if ((e = hipEventCreate(&e0)) != hipSuccess) return e;
@@ -776,8 +853,13 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
                                                                       spill_threads);
             if (search_events && (e = hipEventRecord(e1, stream)) != hipSuccess) return e;
         }
-        walk_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, b, cap, regions, rt, ws.spill, spill_threads);
-        bounce_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, b, sl, cap, regions, ws.contrib);
+        if (with_run) {
+            walk_kernel<true><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, b, cap, regions, rt, ws.spill, spill_threads);
+            bounce_kernel<true><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, b, sl, cap, regions, ws.contrib);
+        } else {
+            walk_kernel<false><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, b, cap, regions, rt, ws.spill, spill_threads);
+            bounce_kernel<false><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, b, sl, cap, regions, ws.contrib);
+        }
     }
     accumulate_kernel<<<blocks_for(geo.npp), kBlock, 0, stream>>>(geo, cam.width, sample_count, ws.contrib, d_accum);
     return hipGetLastError();

@@ -89,7 +89,7 @@ struct DNode {
     uint32_t mesh_id;
     uint32_t parent;  // nearest enclosing collection / transform node, or 0xFFFFFFFF
     uint32_t depth;   // number of enclosing collection / transform nodes
-    uint32_t mesh_ordinal; // MESH: how many mesh nodes precede this one in the array
+    uint32_t mesh_ordinal; // MESH: how many mesh nodes outside the instance run precede this one in the array
     uint32_t only_mesh;    // TRANSFORM whose subtree is one mesh node (behind kd_tree nodes or not): that
                            // mesh node's ordinal; 0xFFFFFFFF otherwise
     // TRANSFORM (transform.rs:33-40 plus the per-ray normal_matrix() of ray.rs:29)
@@ -127,14 +127,53 @@ struct MeshTarget {
     uint32_t chain[kMaxGraphDepth];
 };
 
+// ---- instance run -----------------------------------------------------------
+// A scene that places one mesh many times does it with a collection whose
+// children are transform -> (kd_tree ->) mesh subtrees.  The reference visits
+// them one after the other (node_collection.rs:43-55); here a run of such
+// children directly under the root collection gets a bounding-volume tree over
+// the children's world-space boxes, so a ray only meets the children whose box
+// it pierces.  The run's result is what the sequential visit yields: the smallest
+// t, the earliest child among equal t.
+struct RunChild {
+    uint32_t transform_node; // the child: a transform node ...
+    uint32_t mesh_node;      // ... whose subtree ends in this mesh node
+    uint32_t mesh_id;
+    uint32_t pad;
+};
+// Nodes in depth-first order.  A ray that pierces an inner node's box goes on to
+// the next node, one that misses goes to `skip`; a pierced leaf names a child.
+struct alignas(16) TlasNode {
+    float bmin[3];
+    uint32_t skip;
+    float bmax[3];
+    uint32_t child; // kTlasInner for inner nodes
+};
+constexpr uint32_t kTlasInner = 0xFFFFFFFFu;
+struct DRun {
+    const TlasNode* tlas;
+    const RunChild* children; // in child order
+    uint32_t tlas_count;
+    uint32_t child_count;     // 0: the scene has no run
+    uint32_t first_node;      // node index of the first child
+    uint32_t end_node;        // one past the last child's subtree
+};
+// A ray's searches within the run form a chain through the job list: job_c.w of
+// a job = the previous job of the same ray (index within the region), the ray's
+// head = its last job.
+constexpr uint32_t kRunNone = 0xFFFFFFFFu;    // end of chain / no candidate child
+constexpr uint32_t kRunInPlace = 0xFFFFFFFEu; // the region's job list was full: search while walking
+constexpr uint32_t kRunJobFlag = 0x80000000u; // job_c.z of a run job = flag | child index
+
 struct DScene {
     const DNode* nodes;
     uint32_t node_count;
     const DMesh* meshes;
     const DMaterial* materials;
     uint32_t mesh_count, material_count;
-    const MeshTarget* targets; // the mesh nodes in array order
+    const MeshTarget* targets; // the mesh nodes outside the run, in array order
     uint32_t target_count;
+    DRun run;
 };
 
 // Camera::get_ray inputs with the per-task constants precomputed on the host.

@@ -71,11 +71,12 @@ def shard_opts(task: RenderTask, world: int, rank: int, mode: str, seed: int = 0
 
 
 def render_sharded(render_accumulate: Callable[[RenderTask, RenderOpts, "object"], None], task: RenderTask,
-                   accum, mode: str = "samples", seed: int = 0, group=None):
+                   accum, mode: str = "samples", seed: int = 0, group=None, stage_on_host: bool = False):
     """Renders this rank's share into `accum` (a zeroed torch tensor of W*H*3 f32 on
     the rank's device, camera-space layout) and sums all ranks' buffers onto rank 0.
     `render_accumulate(task, opts, accum)` must add the samples it renders into
-    `accum`.  Returns `accum` (complete on rank 0 only)."""
+    `accum`.  Returns `accum` (complete on rank 0 only).  `stage_on_host` sums through
+    a host copy, for process groups whose backend cannot reduce device tensors (gloo)."""
     import torch.distributed as dist
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -84,7 +85,12 @@ def render_sharded(render_accumulate: Callable[[RenderTask, RenderOpts, "object"
     if opts is not None:
         render_accumulate(sub, opts, accum)
     if world > 1:
-        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM, group=group)
+        if stage_on_host:
+            host = accum.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM, group=group)
+            accum.copy_(host)
+        else:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM, group=group)
     return accum
 
 

@@ -145,11 +145,19 @@ def test_wire_bytes():
     assert np.array_equal(P.RenderedImage.from_bytes(raw).image, img)
 
 
-def test_more_mesh_nodes_than_result_arrays(oracle, tmp_path):
-    """Twenty mesh nodes: the first sixteen are searched ahead of the walk, the last
-    four inside the walk kernel.  Closest hits and a small render against the oracle."""
+@pytest.mark.parametrize("run_min", ["0", None])
+def test_more_mesh_nodes_than_result_arrays(oracle, tmp_path, monkeypatch, run_min):
+    """Twenty mesh nodes.  Walked one after the other (run_min "0"): the first sixteen
+    are searched ahead of the walk, the last four inside the walk kernel.  By default
+    the twenty children form an instance run.  Closest hits and a small render against
+    the oracle."""
     import json
     import shutil
+
+    if run_min is None:
+        monkeypatch.delenv("PATHTRACING_AMD_INSTANCE_RUN_MIN", raising=False)
+    else:
+        monkeypatch.setenv("PATHTRACING_AMD_INSTANCE_RUN_MIN", run_min)
 
     root = str(tmp_path / "many")
     shutil.copytree(H.SCENE_DATA, root)
