@@ -134,33 +134,47 @@ struct PtScene {
         hip_check(hipMalloc(reinterpret_cast<void**>(&ws.ray_total), 2 * sizeof(uint64_t)), "hipMalloc ray_total");
     }
     // Queues, results and contributions for batches of `samples` samples of nbx x nby pixel blocks.
-    void ensure_workspace(uint32_t nbx, uint32_t nby, uint32_t samples) {
+    // False: the device has not that much memory left (nothing is held then).
+    bool ensure_workspace(uint32_t nbx, uint32_t nby, uint32_t samples) {
         ensure_trace_state();
         uint64_t paths = (uint64_t)nbx * nby * 64 * samples;
         uint32_t waves = ws.persistent_blocks * (ptk::kTraceBlock / 64);
         uint64_t records = (uint64_t)ptk::queue_region_capacity(nbx, nby, samples, waves) * waves;
-        if (records <= ws.capacity_paths && paths <= ws.contrib_paths) return;
+        if (records <= ws.capacity_paths && paths <= ws.contrib_paths) return true;
         free_workspace();
+        bool ok = true;
+        auto alloc = [&](auto** p, uint64_t bytes) {
+            if (!ok) return;
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(p), bytes ? bytes : 16);
+            if (e == hipErrorOutOfMemory) {
+                (void)hipGetLastError(); // the failure is handled here: clear the runtime's sticky record of it
+                *p = nullptr;
+                ok = false;
+                return;
+            }
+            hip_check(e, "hipMalloc workspace");
+        };
         for (int q = 0; q < 2; q++)
-            for (int k = 0; k < 3; k++)
-                hip_check(hipMalloc(reinterpret_cast<void**>(&ws.queue[q][k]), records * sizeof(float4)), "hipMalloc queue");
+            for (int k = 0; k < 3; k++) alloc(&ws.queue[q][k], records * sizeof(float4));
         uint32_t result_arrays = std::min<uint32_t>((uint32_t)targets.size(), (uint32_t)ptk::kMaxDeferred);
         ws.job_records = records * (result_arrays + ws.run_slots);
         if (ws.job_records)
-            for (int k = 0; k < 3; k++)
-                hip_check(hipMalloc(reinterpret_cast<void**>(&ws.jobs[k]), ws.job_records * sizeof(float4)), "hipMalloc jobs");
+            for (int k = 0; k < 3; k++) alloc(&ws.jobs[k], ws.job_records * sizeof(float4));
         if (ws.run_slots) {
-            hip_check(hipMalloc(reinterpret_cast<void**>(&ws.run_head), records * sizeof(uint32_t)), "hipMalloc run heads");
-            hip_check(hipMalloc(reinterpret_cast<void**>(&ws.run_res), ws.job_records * sizeof(float4)), "hipMalloc run results");
+            alloc(&ws.run_head, records * sizeof(uint32_t));
+            alloc(&ws.run_res, ws.job_records * sizeof(float4));
         }
-        for (uint32_t k = 0; k < result_arrays; k++)
-            hip_check(hipMalloc(reinterpret_cast<void**>(&ws.results[k]), records * sizeof(float4)), "hipMalloc results");
-        for (int k = 0; k < 2; k++)
-            hip_check(hipMalloc(reinterpret_cast<void**>(&ws.hits[k]), records * sizeof(float4)), "hipMalloc hits");
-        hip_check(hipMalloc(reinterpret_cast<void**>(&ws.hit_uv_y), records * sizeof(float)), "hipMalloc hits");
-        hip_check(hipMalloc(reinterpret_cast<void**>(&ws.contrib), paths * 3 * sizeof(float)), "hipMalloc contrib");
+        for (uint32_t k = 0; k < result_arrays; k++) alloc(&ws.results[k], records * sizeof(float4));
+        for (int k = 0; k < 2; k++) alloc(&ws.hits[k], records * sizeof(float4));
+        alloc(&ws.hit_uv_y, records * sizeof(float));
+        alloc(&ws.contrib, paths * 3 * sizeof(float));
+        if (!ok) {
+            free_workspace();
+            return false;
+        }
         ws.capacity_paths = records;
         ws.contrib_paths = paths;
+        return true;
     }
     ~PtScene() {
         free_workspace();
@@ -563,17 +577,27 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
         w = std::min(o.tile_w, cam.width - x0);
         h = std::min(o.tile_h, cam.height - y0);
     }
-    uint64_t budget = o.paths_per_batch ? o.paths_per_batch : (16ull << 20);
+    // Path slots per batch.  Bigger batches are faster (fewer launches whose last waves run alone, more
+    // samples of a pixel block next to each other); a slot costs about 210 bytes of queues, nine times
+    // the job records on top for scenes with an instance run.  The default is halved until it fits.
+    uint64_t budget = o.paths_per_batch ? o.paths_per_batch : ((scene->ws.run_slots ? 32ull : 128ull) << 20);
     if (budget < 64) budget = 64;
-    // Bands of whole 8-pixel rows such that one sample of a band fits the budget.
     uint32_t nbx = (w + 7) / 8;
     uint64_t slots_per_block_row = (uint64_t)nbx * 64;
-    uint32_t band_block_rows = (uint32_t)std::max<uint64_t>(1, budget / slots_per_block_row);
     uint32_t total_block_rows = (h + 7) / 8;
-    if (band_block_rows > total_block_rows) band_block_rows = total_block_rows;
-    uint64_t band_slots = (uint64_t)band_block_rows * slots_per_block_row;
-    uint32_t samples_per_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / band_slots, task->iterations ? task->iterations : 1));
-    scene->ensure_workspace(nbx, band_block_rows, samples_per_batch);
+    uint32_t band_block_rows = 0, samples_per_batch = 0;
+    for (;;) {
+        // bands of whole 8-pixel rows such that one sample of a band fits the budget
+        band_block_rows = (uint32_t)std::min<uint64_t>(total_block_rows, std::max<uint64_t>(1, budget / slots_per_block_row));
+        uint64_t band_slots = (uint64_t)band_block_rows * slots_per_block_row;
+        samples_per_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / band_slots, task->iterations ? task->iterations : 1));
+        // a batch indexes its path slots with 32 bits
+        while ((uint64_t)samples_per_batch * band_slots > 0xFFFFFFFFull && samples_per_batch > 1) samples_per_batch /= 2;
+        if (scene->ensure_workspace(nbx, band_block_rows, samples_per_batch)) break;
+        if (o.paths_per_batch || budget <= (1ull << 20))
+            throw Error(PT_ERR_DEVICE, "out of device memory for the render's queues (paths_per_batch " + std::to_string(budget) + ")");
+        budget /= 2;
+    }
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (stats) {
