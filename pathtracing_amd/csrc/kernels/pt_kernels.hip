@@ -374,27 +374,55 @@ bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList sl, u
     const uint32_t waves = (gridDim.x * kBlock) >> 6;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     unsigned long long listed = 0;
+    // the first kLdsMaterials materials are read from a copy in LDS: one dependent trip to memory less per hit
+    constexpr uint32_t kLdsMaterials = 32;
+    __shared__ DMaterial lds_materials[kLdsMaterials];
+    const uint32_t n_lds = p.scene.material_count < kLdsMaterials ? p.scene.material_count : kLdsMaterials;
+    static_assert(sizeof(DMaterial) % 4 == 0, "DMaterial is copied by dwords");
+    for (uint32_t i = threadIdx.x; i < n_lds * (uint32_t)(sizeof(DMaterial) / 4); i += kBlock)
+        reinterpret_cast<uint32_t*>(lds_materials)[i] = reinterpret_cast<const uint32_t*>(p.scene.materials)[i];
+    __syncthreads();
 
     for (uint32_t r = wave; r < regions; r += waves) {
         const size_t base = (size_t)r * cap;
         const uint32_t n_items = b.ray_counts[r];
         uint32_t out_pos = 0u, job_pos = 0u, run_used = 0u;
+        // The records of a chunk are fetched while the chunk before it is worked on: the material and
+        // the texel of a hit are two more dependent fetches, and a wave has nothing else to wait with.
+        struct Records {
+            float4 rb, rc, ha, hb;
+            float hc;
+        };
+        auto fetch = [&](uint32_t first) {
+            Records rec;
+            const uint32_t item = first + lane;
+            if (item < n_items) {
+                rec.rb = b.ray_b[base + item];
+                rec.rc = b.ray_c[base + item];
+                rec.ha = b.hit_a[base + item];
+                rec.hb = b.hit_b[base + item];
+                rec.hc = b.hit_c[base + item];
+            }
+            return rec;
+        };
+        Records upcoming = fetch(0u);
         for (uint32_t first = 0; first < n_items; first += 64u) {
             const uint32_t item = first + lane;
+            const Records rec = upcoming;
+            if (first + 64u < n_items) upcoming = fetch(first + 64u);
             bool emit = false;
             Ray nray;
             V3 nmult = mk3(0, 0, 0);
             uint32_t path = 0, rng_counter = 0;
             if (item < n_items) {
-                float4 rb = b.ray_b[base + item], rc = b.ray_c[base + item];
-                float4 ha = b.hit_a[base + item];
+                const float4 rb = rec.rb, rc = rec.rc, ha = rec.ha;
                 path = __float_as_uint(rb.w);
                 rng_counter = __float_as_uint(rc.w);
                 const uint32_t tag = __float_as_uint(ha.w);
                 V3 color = mk3(0, 0, 0);
                 bool finished = true;
                 if (tag != 0xFFFFFFFFu) {
-                    float4 hb = b.hit_b[base + item];
+                    const float4 hb = rec.hb;
                     Hit cur;
                     cur.hit = 1u;
                     cur.hit_inside = tag >> 31;
@@ -404,7 +432,7 @@ bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList sl, u
                     cur.tri_index = 0u;
                     cur.point = mk3(ha.x, ha.y, ha.z);
                     cur.normal = mk3(hb.x, hb.y, hb.z);
-                    cur.uv = mk2(hb.w, b.hit_c[base + item]);
+                    cur.uv = mk2(hb.w, rec.hc);
                     V3 mult = mk3(rc.x, rc.y, rc.z);
                     uint32_t s_local = path / p.geo.npp, q = path % p.geo.npp;
                     uint32_t x, y;
@@ -414,7 +442,8 @@ bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList sl, u
                     rng.key = stream_key(p.seed, stream_id(p.sample_first + s_local, (uint64_t)x + (uint64_t)y * p.cam.width));
                     rng.counter = rng_counter;
                     V3 av, dir;
-                    bool is_color = material_get_color(p.scene.materials[cur.material_id], mk3(rb.x, rb.y, rb.z), cur, rng, &av, &dir);
+                    const DMaterial* material = cur.material_id < n_lds ? &lds_materials[cur.material_id] : &p.scene.materials[cur.material_id];
+                    bool is_color = material_get_color(*material, mk3(rb.x, rb.y, rb.z), cur, rng, &av, &dir);
                     rng_counter = rng.counter;
                     if (is_color) {
                         color = mult * av;
