@@ -46,6 +46,8 @@ def assert_hits_identical(got: np.ndarray, want: np.ndarray, what: str = "") -> 
     assert got.shape == want.shape
     assert np.array_equal(got["hit"], want["hit"]), f"{what}: hit flags differ at {np.nonzero(got['hit'] != want['hit'])[0][:8]}"
     m = want["hit"] == 1
+    if not m.any():
+        return
     for name in ("hit_inside", "node_index", "tri_index", "material_id"):
         bad = np.nonzero(got[name][m] != want[name][m])[0]
         assert bad.size == 0, f"{what}: {name} differs for {bad.size} hits, first {bad[:8]}"
