@@ -346,7 +346,24 @@ InstanceRun find_instance_run(const std::vector<ptk::DNode>& nodes) {
         }
         if (cur.children.empty()) cur.first_node = c;
         cur.end_node = nodes[c].end;
-        cur.children.push_back(ptk::RunChild{c, mesh_node, nodes[mesh_node].mesh_id, 0u});
+        ptk::RunChild rc{};
+        rc.transform_node = c;
+        rc.mesh_node = mesh_node;
+        rc.mesh_id = nodes[mesh_node].mesh_id;
+        rc.material_id = nodes[mesh_node].material_id;
+        auto pack = [](const ptk::M4& m, const ptk::M3& n, float* m16, float* n12) {
+            memcpy(m16, m.m, 16 * sizeof(float));
+            const ptk::V3* rows[3] = {&n.row0, &n.row1, &n.row2};
+            for (int r = 0; r < 3; r++) {
+                n12[4 * r] = rows[r]->x;
+                n12[4 * r + 1] = rows[r]->y;
+                n12[4 * r + 2] = rows[r]->z;
+                n12[4 * r + 3] = 0.0f;
+            }
+        };
+        pack(nodes[c].matrix_inverse, nodes[c].inverse_normal_matrix, rc.inverse, rc.inverse_normal);
+        pack(nodes[c].matrix, nodes[c].normal_matrix, rc.matrix, rc.normal);
+        cur.children.push_back(rc);
     }
     close();
     return best;

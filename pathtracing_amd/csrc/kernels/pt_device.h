@@ -628,22 +628,6 @@ __device__ __forceinline__ Ray transform_ray_c(const __attribute__((address_spac
     return o;
 }
 
-// Ray::apply_transform (ray.rs:21-37) with the node read by this lane alone: inside an
-// instance run the lanes of a wave are at different children.
-__device__ __forceinline__ Ray transform_ray_g(const DNode& node, const Ray& r) {
-    V3 min_point = r.min * r.direction + r.source;
-    V3 max_point = r.max * r.direction + r.source;
-    V3 s = mul_point(node.matrix_inverse, r.source);
-    V3 mn = mul_point(node.matrix_inverse, min_point);
-    V3 mx = mul_point(node.matrix_inverse, max_point);
-    Ray o;
-    o.source = s;
-    o.direction = mul(node.inverse_normal_matrix, r.direction);
-    o.min = length(mn - s);
-    o.max = length(mx - s);
-    return o;
-}
-
 // ---- instance run (DRun) -----------------------------------------------------
 // Cursor over the children of the run whose world-space box the ray pierces.
 struct RunCursor {
@@ -679,24 +663,70 @@ __device__ __forceinline__ uint32_t run_next(const DRun& run, const Ray& world, 
     return kRunNone;
 }
 
+// A child's table entry: ids, and the ray of `world` in the child's space
+// (Ray::apply_transform, ray.rs:21-37, on the packed copy of the transform node).
+struct RunChildIds {
+    uint32_t transform_node, mesh_node, mesh_id, material_id;
+};
+__device__ __forceinline__ void unpack_rows(GlobalF4Ptr rows, int first, M4* m, M3* n) {
+    for (int r = 0; r < 4; r++) {
+        float4 v = rows[first + r];
+        m->m[r][0] = v.x;
+        m->m[r][1] = v.y;
+        m->m[r][2] = v.z;
+        m->m[r][3] = v.w;
+    }
+    float4 a = rows[first + 4], b = rows[first + 5], c = rows[first + 6];
+    n->row0 = mk3(a.x, a.y, a.z);
+    n->row1 = mk3(b.x, b.y, b.z);
+    n->row2 = mk3(c.x, c.y, c.z);
+}
+__device__ __forceinline__ RunChildIds run_child_ids(const DRun& run, uint32_t k) {
+    float4 v = global_f4(run.children + k)[0];
+    RunChildIds ids;
+    ids.transform_node = __float_as_uint(v.x);
+    ids.mesh_node = __float_as_uint(v.y);
+    ids.mesh_id = __float_as_uint(v.z);
+    ids.material_id = __float_as_uint(v.w);
+    return ids;
+}
+__device__ __forceinline__ Ray run_child_ray(const DRun& run, uint32_t k, const Ray& r) {
+    M4 inv;
+    M3 ninv;
+    unpack_rows(global_f4(run.children + k), 1, &inv, &ninv);
+    V3 min_point = r.min * r.direction + r.source;
+    V3 max_point = r.max * r.direction + r.source;
+    V3 s = mul_point(inv, r.source);
+    V3 mn = mul_point(inv, min_point);
+    V3 mx = mul_point(inv, max_point);
+    Ray o;
+    o.source = s;
+    o.direction = mul(ninv, r.direction);
+    o.min = length(mn - s);
+    o.max = length(mx - s);
+    return o;
+}
+
 // What the run's child k returns for `world` (transform.rs:45-66 around
 // hierarchy/mesh.rs:61-66), given the closest triangle of its mesh for the ray in
 // the mesh's space.
 __device__ __forceinline__ void run_child_hit(const DScene& sc, uint32_t k, const Ray& world, float t, uint32_t slot,
                                               uint32_t orig, Hit* h) {
-    const RunChild rc = sc.run.children[k];
-    const DNode& tn = sc.nodes[rc.transform_node];
-    Ray local = transform_ray_g(tn, world);
-    const DMesh& mesh = sc.meshes[rc.mesh_id];
+    const RunChildIds ids = run_child_ids(sc.run, k);
+    Ray local = run_child_ray(sc.run, k, world);
+    const DMesh& mesh = sc.meshes[ids.mesh_id];
     DNode nd;
-    nd.material_id = sc.nodes[rc.mesh_node].material_id;
-    nd.mesh_id = rc.mesh_id;
-    mesh_result(mesh, nd, rc.mesh_node, local, true, t, mesh.tris + slot, orig, h);
+    nd.material_id = ids.material_id;
+    nd.mesh_id = ids.mesh_id;
+    mesh_result(mesh, nd, ids.mesh_node, local, true, t, mesh.tris + slot, orig, h);
     if (h->hit) {
-        V3 point = mul_point(tn.matrix, h->point);
+        M4 fwd;
+        M3 nfwd;
+        unpack_rows(global_f4(sc.run.children + k), 8, &fwd, &nfwd);
+        V3 point = mul_point(fwd, h->point);
         h->t = length(point - world.source);
         h->point = point;
-        h->normal = mul(tn.normal_matrix, h->normal);
+        h->normal = mul(nfwd, h->normal);
     }
 }
 
@@ -751,10 +781,9 @@ __device__ __forceinline__ void walk_run(const DScene& sc, const Ray& world, con
         RunCursor c;
         run_begin(sc.run, world, true, c);
         for (uint32_t k = run_next(sc.run, world, c); k != kRunNone; k = run_next(sc.run, world, c)) {
-            const RunChild rc = sc.run.children[k];
-            Ray local = transform_ray_g(sc.nodes[rc.transform_node], world);
+            Ray local = run_child_ray(sc.run, k, world);
             TravState ts;
-            search_in_place(sc.meshes[rc.mesh_id], local, st, ts);
+            search_in_place(sc.meshes[run_child_ids(sc.run, k).mesh_id], local, st, ts);
             if (ts.found != 0u) {
                 Hit h;
                 run_child_hit(sc, k, world, ts.tbest, ts.best_slot, ts.best_orig, &h);

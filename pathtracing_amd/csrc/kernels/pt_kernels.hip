@@ -155,9 +155,8 @@ __device__ __forceinline__ void list_searches(const DScene& scene, const SearchL
         Ray ray = world;
         uint32_t mesh_id = 0u;
         if (k != kRunNone) {
-            const RunChild rc = scene.run.children[k];
-            mesh_id = rc.mesh_id;
-            ray = transform_ray_g(scene.nodes[rc.transform_node], world);
+            mesh_id = run_child_ids(scene.run, k).mesh_id;
+            ray = run_child_ray(scene.run, k, world);
             need = trav_reaches(scene.meshes[mesh_id], ray);
         }
         const unsigned long long mask = __ballot(need);

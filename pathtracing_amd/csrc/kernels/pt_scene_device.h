@@ -135,12 +135,19 @@ struct MeshTarget {
 // the children's world-space boxes, so a ray only meets the children whose box
 // it pierces.  The run's result is what the sequential visit yields: the smallest
 // t, the earliest child among equal t.
-struct RunChild {
+// One child, with what the lanes need of its two nodes packed into 16-byte rows: inside a run
+// every lane is at a different child, so these come by vector loads, not from the node array.
+struct alignas(16) RunChild {
     uint32_t transform_node; // the child: a transform node ...
     uint32_t mesh_node;      // ... whose subtree ends in this mesh node
     uint32_t mesh_id;
-    uint32_t pad;
+    uint32_t material_id;    // of the mesh node
+    float inverse[16];         // the transform node's matrix_inverse, row-major
+    float inverse_normal[12];  // its inverse_normal_matrix, each row padded to four
+    float matrix[16];          // its matrix
+    float normal[12];          // its normal_matrix, rows padded
 };
+static_assert(sizeof(RunChild) == 240, "RunChild is read as fifteen 16-byte rows");
 // Nodes in depth-first order.  A ray that pierces an inner node's box goes on to
 // the next node, one that misses goes to `skip`; a pierced leaf names a child.
 struct alignas(16) TlasNode {
