@@ -339,7 +339,16 @@ InstanceRun find_instance_run(const std::vector<ptk::DNode>& nodes) {
         cur = InstanceRun();
     };
     for (uint32_t c = 1; c < nodes[0].end; c = nodes[c].end) {
-        uint32_t mesh_node = (nodes[c].type == PT_NODE_TRANSFORM && keeps_lines(nodes[c].matrix)) ? single_mesh_below(nodes, c) : 0xFFFFFFFFu;
+        // a mesh under a line-keeping transform, or a mesh as it is (behind kd_tree nodes or not)
+        uint32_t mesh_node = 0xFFFFFFFFu;
+        bool transformed = nodes[c].type == PT_NODE_TRANSFORM;
+        if (transformed) {
+            if (keeps_lines(nodes[c].matrix)) mesh_node = single_mesh_below(nodes, c);
+        } else {
+            uint32_t j = c;
+            while (j < nodes.size() && nodes[j].type == PT_NODE_KD_TREE) j++;
+            if (j < nodes.size() && nodes[j].type == PT_NODE_MESH && nodes[c].end == j + 1) mesh_node = j;
+        }
         if (mesh_node == 0xFFFFFFFFu) {
             close();
             continue;
@@ -347,7 +356,7 @@ InstanceRun find_instance_run(const std::vector<ptk::DNode>& nodes) {
         if (cur.children.empty()) cur.first_node = c;
         cur.end_node = nodes[c].end;
         ptk::RunChild rc{};
-        rc.transform_node = c;
+        rc.transform_node = transformed ? c : ptk::kRunNoTransform;
         rc.mesh_node = mesh_node;
         rc.mesh_id = nodes[mesh_node].mesh_id;
         rc.material_id = nodes[mesh_node].material_id;
@@ -361,8 +370,10 @@ InstanceRun find_instance_run(const std::vector<ptk::DNode>& nodes) {
                 n12[4 * r + 3] = 0.0f;
             }
         };
-        pack(nodes[c].matrix_inverse, nodes[c].inverse_normal_matrix, rc.inverse, rc.inverse_normal);
-        pack(nodes[c].matrix, nodes[c].normal_matrix, rc.matrix, rc.normal);
+        if (transformed) {
+            pack(nodes[c].matrix_inverse, nodes[c].inverse_normal_matrix, rc.inverse, rc.inverse_normal);
+            pack(nodes[c].matrix, nodes[c].normal_matrix, rc.matrix, rc.normal);
+        }
         cur.children.push_back(rc);
     }
     close();
@@ -383,7 +394,9 @@ std::vector<ptk::TlasNode> build_run_tree(const InstanceRun& run, const std::vec
     std::vector<Box> boxes(n);
     for (size_t k = 0; k < n; k++) {
         const ptk::DMesh& mesh = meshes[run.children[k].mesh_id];
-        const ptk::M4& m = nodes[run.children[k].transform_node].matrix;
+        ptk::M4 m{};
+        for (int d = 0; d < 4; d++) m.m[d][d] = 1.0f;
+        if (run.children[k].transform_node != ptk::kRunNoTransform) m = nodes[run.children[k].transform_node].matrix;
         Box b;
         for (int a = 0; a < 3; a++) b.lo[a] = INFINITY, b.hi[a] = -INFINITY;
         for (int corner = 0; corner < 8; corner++) {

@@ -690,7 +690,8 @@ __device__ __forceinline__ RunChildIds run_child_ids(const DRun& run, uint32_t k
     ids.material_id = __float_as_uint(v.w);
     return ids;
 }
-__device__ __forceinline__ Ray run_child_ray(const DRun& run, uint32_t k, const Ray& r) {
+__device__ __forceinline__ Ray run_child_ray(const DRun& run, uint32_t k, const RunChildIds& ids, const Ray& r) {
+    if (ids.transform_node == kRunNoTransform) return r;
     M4 inv;
     M3 ninv;
     unpack_rows(global_f4(run.children + k), 1, &inv, &ninv);
@@ -713,13 +714,13 @@ __device__ __forceinline__ Ray run_child_ray(const DRun& run, uint32_t k, const 
 __device__ __forceinline__ void run_child_hit(const DScene& sc, uint32_t k, const Ray& world, float t, uint32_t slot,
                                               uint32_t orig, Hit* h) {
     const RunChildIds ids = run_child_ids(sc.run, k);
-    Ray local = run_child_ray(sc.run, k, world);
+    Ray local = run_child_ray(sc.run, k, ids, world);
     const DMesh& mesh = sc.meshes[ids.mesh_id];
     DNode nd;
     nd.material_id = ids.material_id;
     nd.mesh_id = ids.mesh_id;
     mesh_result(mesh, nd, ids.mesh_node, local, true, t, mesh.tris + slot, orig, h);
-    if (h->hit) {
+    if (h->hit && ids.transform_node != kRunNoTransform) {
         M4 fwd;
         M3 nfwd;
         unpack_rows(global_f4(sc.run.children + k), 8, &fwd, &nfwd);
@@ -781,9 +782,10 @@ __device__ __forceinline__ void walk_run(const DScene& sc, const Ray& world, con
         RunCursor c;
         run_begin(sc.run, world, true, c);
         for (uint32_t k = run_next(sc.run, world, c); k != kRunNone; k = run_next(sc.run, world, c)) {
-            Ray local = run_child_ray(sc.run, k, world);
+            const RunChildIds ids = run_child_ids(sc.run, k);
+            Ray local = run_child_ray(sc.run, k, ids, world);
             TravState ts;
-            search_in_place(sc.meshes[run_child_ids(sc.run, k).mesh_id], local, st, ts);
+            search_in_place(sc.meshes[ids.mesh_id], local, st, ts);
             if (ts.found != 0u) {
                 Hit h;
                 run_child_hit(sc, k, world, ts.tbest, ts.best_slot, ts.best_orig, &h);

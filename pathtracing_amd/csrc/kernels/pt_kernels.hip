@@ -155,8 +155,9 @@ __device__ __forceinline__ void list_searches(const DScene& scene, const SearchL
         Ray ray = world;
         uint32_t mesh_id = 0u;
         if (k != kRunNone) {
-            mesh_id = run_child_ids(scene.run, k).mesh_id;
-            ray = run_child_ray(scene.run, k, world);
+            const RunChildIds ids = run_child_ids(scene.run, k);
+            mesh_id = ids.mesh_id;
+            ray = run_child_ray(scene.run, k, ids, world);
             need = trav_reaches(scene.meshes[mesh_id], ray);
         }
         const unsigned long long mask = __ballot(need);

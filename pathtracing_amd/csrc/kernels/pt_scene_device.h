@@ -131,14 +131,14 @@ struct MeshTarget {
 // A scene that places one mesh many times does it with a collection whose
 // children are transform -> (kd_tree ->) mesh subtrees.  The reference visits
 // them one after the other (node_collection.rs:43-55); here a run of such
-// children directly under the root collection gets a bounding-volume tree over
+// children (and of meshes placed without a transform) directly under the root collection gets a bounding-volume tree over
 // the children's world-space boxes, so a ray only meets the children whose box
 // it pierces.  The run's result is what the sequential visit yields: the smallest
 // t, the earliest child among equal t.
 // One child, with what the lanes need of its two nodes packed into 16-byte rows: inside a run
 // every lane is at a different child, so these come by vector loads, not from the node array.
 struct alignas(16) RunChild {
-    uint32_t transform_node; // the child: a transform node ...
+    uint32_t transform_node; // the child: a transform node (kRunNoTransform: the mesh stands in the collection as it is) ...
     uint32_t mesh_node;      // ... whose subtree ends in this mesh node
     uint32_t mesh_id;
     uint32_t material_id;    // of the mesh node
@@ -157,6 +157,7 @@ struct alignas(16) TlasNode {
     uint32_t child; // kTlasInner for inner nodes
 };
 constexpr uint32_t kTlasInner = 0xFFFFFFFFu;
+constexpr uint32_t kRunNoTransform = 0xFFFFFFFFu;
 struct DRun {
     const TlasNode* tlas;
     const RunChild* children; // in child order

@@ -34,8 +34,8 @@ def _plane(point, normal, tangent, bitangent, mat):
 
 def write_run_scene(directory, crowded=False):
     """crowded=False: a light, four instances no run can hold, a plane, a short run of
-    five (walked child by child), a sphere, a run of 34 on a jittered grid with two exact
-    duplicates and overlapping neighbours, a nested collection, a back wall.
+    five (walked child by child), a sphere, a run of 36 on a jittered grid with two exact
+    duplicates, two untransformed meshes and overlapping neighbours, a nested collection, a back wall.
     crowded=True: 40 instances stacked on nearly the same spot and filling the frame, so
     every camera ray meets all forty boxes (five times the job slots set aside per ray: the
     regions' job lists fill up and the remaining searches happen while walking)."""
@@ -71,6 +71,10 @@ def write_run_scene(directory, crowded=False):
             m = H._trs(rnd.uniform(0, 2 * math.pi), (sc, sc, sc),
                        (x + rnd.uniform(-0.4, 0.4), -1.5 + rnd.uniform(0, 1.5), z + rnd.uniform(-0.4, 0.4)))
             children.append(_instance(i, m, kd=i % 4 == 1))
+            if i == 9:  # meshes standing in the collection without a transform belong to the run as well
+                children.append({"type": "mesh", "path": "./gem.obj", "material": "./materials/mat4.json"})
+                children.append({"type": "kd_tree", "path": "./cube.tree",
+                                 "child": {"type": "mesh", "path": "./cube.obj", "material": "./materials/mat5.json"}})
             if i == 5 or i == 20:  # an exact duplicate right behind it, another material: the first one wins every tie
                 dup = _instance(i, m)
                 dup["child"]["material"] = "./materials/mat0.json" if i == 5 else "./materials/mat2.json"
