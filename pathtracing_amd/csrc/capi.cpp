@@ -810,6 +810,26 @@ PtStatus pt_scene_create(const PtSceneDesc* desc, int device, PtScene** out_scen
         s->d.material_count = desc->material_count;
         s->d.targets = s->upload(s->targets);
         s->d.target_count = (uint32_t)s->targets.size();
+        s->d.flat_root = 0;
+        if (nodes[0].type == PT_NODE_COLLECTION) {
+            bool flat = true;
+            for (uint32_t c = 1; c < nodes[0].end && flat; c = nodes[c].end) {
+                switch (nodes[c].type) {
+                case PT_NODE_SPHERE:
+                case PT_NODE_PLANE: break;
+                case PT_NODE_TRANSFORM: flat = single_mesh_below(nodes, c) != 0xFFFFFFFFu; break;
+                case PT_NODE_MESH:
+                case PT_NODE_KD_TREE: {
+                    uint32_t j = c;
+                    while (j < nodes.size() && nodes[j].type == PT_NODE_KD_TREE) j++;
+                    flat = j < nodes.size() && nodes[j].type == PT_NODE_MESH && nodes[c].end == j + 1;
+                    break;
+                }
+                default: flat = false;
+                }
+            }
+            s->d.flat_root = flat ? 1u : 0u;
+        }
         memset(&s->d.run, 0, sizeof(s->d.run));
         if (!run.children.empty()) {
             std::vector<ptk::TlasNode> tlas = build_run_tree(run, nodes, meshes);

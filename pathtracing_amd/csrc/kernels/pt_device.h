@@ -920,6 +920,93 @@ __device__ __forceinline__ int walk(const DScene& sc, WalkState& w, Hit& cur, bo
     return status;
 }
 
+// scene.hierarchy.trace_ray for a scene whose root collection holds only leaves and transforms
+// over one mesh (DScene::flat_root): one wave-uniform loop over the children, the ray and the
+// running best in registers, nothing saved or resumed.  Arithmetic and comparisons are those of
+// walk(): node_collection.rs:43-55 around sphere.rs / plane.rs / transform.rs + hierarchy/mesh.rs.
+// `res[m][index]` = the closest triangle of the scene's m-th mesh node for this ray (m below
+// `deferred`; further mesh nodes are searched here); `live_meshes`, `run` as in walk().
+template <bool kRun>
+__device__ __forceinline__ void walk_flat(const DScene& sc, const Ray& world, float4* const* res, size_t index,
+                                          uint32_t deferred, uint32_t live_meshes, const RunLookup* run, TravStack& st,
+                                          Hit* out) {
+    ConstNodePtr nodes = const_nodes(sc);
+    Hit best;
+    best.hit = 0u;
+    best.hit_inside = 0u;
+    best.t = f32_inf();
+    best.material_id = 0u;
+    best.node_index = 0xFFFFFFFFu;
+    best.tri_index = 0xFFFFFFFFu;
+    best.point = mk3(0, 0, 0);
+    best.normal = mk3(0, 0, 0);
+    best.uv = mk2(0, 0);
+    const uint32_t n = sc.node_count;
+    for (uint32_t i = 1; i < n;) {
+        Hit cur;
+        cur.hit = 0u;
+        cur.hit_inside = 0u;
+        cur.t = f32_inf();
+        if (kRun && sc.run.child_count != 0u && i == sc.run.first_node) {
+            walk_run(sc, world, run, st, &cur);
+            i = sc.run.end_node;
+        } else {
+            const uint32_t type = nodes[i].type;
+            const uint32_t end = nodes[i].end;
+            if (type == 3u) {
+                DNode nd;
+                nd.center = cv3(nodes[i].center);
+                nd.radius = nodes[i].radius;
+                nd.radius_sqr = nodes[i].radius_sqr;
+                nd.material_id = nodes[i].material_id;
+                typedef const __attribute__((address_space(4))) DMaterial* ConstMaterialPtr;
+                bool want_uv = ((ConstMaterialPtr)(unsigned long long)sc.materials)[nd.material_id].color_is_texture != 0u;
+                sphere_trace(nd, i, world, &cur, want_uv);
+            } else if (type == 4u) {
+                DNode nd;
+                nd.point = cv3(nodes[i].point);
+                nd.normal = cv3(nodes[i].normal);
+                nd.tangent = cv3(nodes[i].tangent);
+                nd.bitangent = cv3(nodes[i].bitangent);
+                nd.material_id = nodes[i].material_id;
+                plane_trace(nd, i, world, &cur);
+            } else {
+                // (transform ->) (kd_tree ->) mesh: the mesh node is the last node of the subtree
+                const uint32_t j = end - 1u;
+                const uint32_t m = nodes[j].mesh_ordinal;
+                if (m >= 32u || ((live_meshes >> m) & 1u) != 0u) {
+                    const bool transformed = type == 1u;
+                    Ray local = transformed ? transform_ray_c(nodes[i], world) : world;
+                    DNode nd;
+                    nd.material_id = nodes[j].material_id;
+                    nd.mesh_id = nodes[j].mesh_id;
+                    const DMesh& mesh = sc.meshes[nd.mesh_id];
+                    TravState ts;
+                    if (m < deferred) {
+                        float4 r = res[m][index];
+                        ts.tbest = r.x;
+                        ts.found = __float_as_uint(r.y);
+                        ts.best_slot = __float_as_uint(r.z);
+                        ts.best_orig = __float_as_uint(r.w);
+                    } else {
+                        search_in_place(mesh, local, st, ts);
+                    }
+                    mesh_result(mesh, nd, j, local, ts.found != 0u, ts.tbest, mesh.tris + ts.best_slot, ts.best_orig, &cur);
+                    if (transformed && cur.hit) {
+                        V3 point = mul_point_c(nodes[i].matrix, cur.point);
+                        cur.t = length(point - world.source);
+                        cur.point = point;
+                        cur.normal = mul_c(nodes[i].normal_matrix, cur.normal);
+                    }
+                }
+            }
+            i = end;
+        }
+        if (cur.hit && cur.t < best.t) best = cur;
+    }
+    *out = best;
+}
+
 // The mesh of the node the walk stopped at.
 __device__ __forceinline__ const DMesh& walk_mesh(const DScene& sc, const WalkState& w) {
     return sc.meshes[const_nodes(sc)[__builtin_amdgcn_readfirstlane(w.i)].mesh_id];

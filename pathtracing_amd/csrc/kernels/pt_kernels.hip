@@ -273,11 +273,10 @@ camera_kernel(RenderParams p, SegmentBuffers b, SearchList sl, uint32_t cap, uin
 // the remaining meshes in place.  The walk keeps two hit records and a ray per lane
 // alive (3 waves per SIMD); everything that can run at full occupancy is left to
 // bounce_kernel.
-#ifndef PT_WALK_OCCUPANCY
-#define PT_WALK_OCCUPANCY 3
-#endif
-template <bool kRun>
-__global__ void __launch_bounds__(kBlock, PT_WALK_OCCUPANCY)
+// Waves per SIMD the kernel is compiled for: four without the instance-run code (128 registers:
+// the loop over a flat root's children and the general walk both fit), three with it.
+template <bool kRun, bool kFlat>
+__global__ void __launch_bounds__(kBlock, kRun ? 3 : 4)
 walk_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions, unsigned long long* ray_total,
             uint32_t* spill, uint32_t spill_threads) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
@@ -328,6 +327,14 @@ walk_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions, un
                 look.head = b.run_head[base + item];
                 look.job_c = b.run_job_c + (size_t)r * b.job_cap;
                 look.run_res = b.run_res + (size_t)r * b.job_cap;
+            }
+            if (kFlat) {
+                walk_flat<kRun>(p.scene, ray, b.res, base + item, (uint32_t)kMaxDeferred, live, have_run ? &look : nullptr, st, &cur);
+                uint32_t tag = cur.hit ? (cur.material_id | (cur.hit_inside << 31)) : 0xFFFFFFFFu;
+                b.hit_a[base + item] = make_float4(cur.point.x, cur.point.y, cur.point.z, __uint_as_float(tag));
+                b.hit_b[base + item] = make_float4(cur.normal.x, cur.normal.y, cur.normal.z, cur.uv.x);
+                b.hit_c[base + item] = cur.uv.y;
+                continue;
             }
             WalkState w;
             TravState ts;
@@ -882,11 +889,16 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
                                                                       spill_threads);
             if (search_events && (e = hipEventRecord(e1, stream)) != hipSuccess) return e;
         }
+        // one loop over the root's children where the scene has that shape (not in the linear-scan mode,
+        // whose searches happen inside the general walk)
+        const bool flat = scene.flat_root != 0u && !brute;
         if (with_run) {
-            walk_kernel<true><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, b, cap, regions, rt, ws.spill, spill_threads);
+            if (flat) walk_kernel<true, true><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, b, cap, regions, rt, ws.spill, spill_threads);
+            else walk_kernel<true, false><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, b, cap, regions, rt, ws.spill, spill_threads);
             bounce_kernel<true><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, b, sl, cap, regions, ws.contrib);
         } else {
-            walk_kernel<false><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, b, cap, regions, rt, ws.spill, spill_threads);
+            if (flat) walk_kernel<false, true><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, b, cap, regions, rt, ws.spill, spill_threads);
+            else walk_kernel<false, false><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, b, cap, regions, rt, ws.spill, spill_threads);
             bounce_kernel<false><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, b, sl, cap, regions, ws.contrib);
         }
     }

@@ -181,6 +181,10 @@ struct DScene {
     uint32_t mesh_count, material_count;
     const MeshTarget* targets; // the mesh nodes outside the run, in array order
     uint32_t target_count;
+    // 1: the root is a collection and each of its children is a sphere, a plane, a (kd_tree ->) mesh
+    // or a transform over a (kd_tree ->) mesh -- the shape of every scene the reference ships.  The
+    // walk kernel then runs one loop over the children instead of the general resumable walk.
+    uint32_t flat_root;
     DRun run;
 };
 
