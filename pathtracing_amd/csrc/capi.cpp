@@ -810,6 +810,8 @@ PtStatus pt_scene_create(const PtSceneDesc* desc, int device, PtScene** out_scen
         s->d.material_count = desc->material_count;
         s->d.targets = s->upload(s->targets);
         s->d.target_count = (uint32_t)s->targets.size();
+        memset(&s->d.mesh0, 0, sizeof(s->d.mesh0));
+        if (!meshes.empty()) s->d.mesh0 = meshes[0];
         s->d.flat_root = 0;
         if (nodes[0].type == PT_NODE_COLLECTION) {
             bool flat = true;

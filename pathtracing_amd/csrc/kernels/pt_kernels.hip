@@ -506,8 +506,11 @@ struct SearchResults {
 // the slowest search of their wave: each lane is a small state machine and the
 // wave hands idle lanes new jobs whenever kRefill searches have finished (search
 // lengths differ by an order of magnitude between neighbouring rays).
+// kOneMesh: the scene has a single mesh, `one`; its node and triangle arrays are then kernel
+// arguments (scalar registers) instead of per-lane state read from the mesh table at every refill.
+template <bool kOneMesh>
 __global__ void __launch_bounds__(kBlock, PT_SEARCH_OCCUPANCY)
-search_kernel(const DMesh* __restrict__ meshes, const float4* __restrict__ job_a, const float4* __restrict__ job_b,
+search_kernel(const DMesh* __restrict__ meshes, DMesh one, const float4* __restrict__ job_a, const float4* __restrict__ job_b,
               const float4* __restrict__ job_c, const uint32_t* __restrict__ job_counts, SearchResults out, uint32_t cap,
               uint32_t job_cap, uint32_t regions, uint32_t* spill, uint32_t spill_threads) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
@@ -523,6 +526,10 @@ search_kernel(const DMesh* __restrict__ meshes, const float4* __restrict__ job_a
     uint32_t next = 0u;
     TravState ts;
     ts.cur = kBvhSentinel;
+    if (kOneMesh) {
+        ts.nodes = one.nodes;
+        ts.tris = one.tris;
+    }
     Ray ray;
     float4* res_out = nullptr;
     bool busy = false;
@@ -552,13 +559,17 @@ search_kernel(const DMesh* __restrict__ meshes, const float4* __restrict__ job_a
                 ray.max = jb.w;
                 uint32_t v = __float_as_uint(jc.x), mesh_id = __float_as_uint(jc.y), m = __float_as_uint(jc.z);
                 res_out = (m & kRunJobFlag) ? out.run_res + j : out.res[m] + ((size_t)region * cap + v);
-                const DMesh& mesh = meshes[mesh_id];
                 // whoever listed the job has already checked the ray against the mesh bounds
                 ts.inv = search_inverse_direction(ray.direction);
                 ts.ray_limit = (ray.max == ray.max) ? ray.max : f32_inf();
-                ts.nodes = mesh.nodes;
-                ts.tris = mesh.tris;
-                ts.cur = mesh.root_ref;
+                if (kOneMesh) {
+                    ts.cur = one.root_ref;
+                } else {
+                    const DMesh& mesh = meshes[mesh_id];
+                    ts.nodes = mesh.nodes;
+                    ts.tris = mesh.tris;
+                    ts.cur = mesh.root_ref;
+                }
                 ts.tbest = f32_inf();
                 ts.best_slot = 0u;
                 ts.best_orig = 0xFFFFFFFFu;
@@ -884,9 +895,14 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
                 search_events->push_back(e1);
                 if ((e = hipEventRecord(e0, stream)) != hipSuccess) return e;
             }
-            search_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(scene.meshes, ws.jobs[0], ws.jobs[1], ws.jobs[2],
-                                                                      ws.job_counts, sr, cap, sl.job_cap, regions, ws.spill,
-                                                                      spill_threads);
+            if (scene.mesh_count == 1u)
+                search_kernel<true><<<ws.persistent_blocks, kBlock, 0, stream>>>(scene.meshes, scene.mesh0, ws.jobs[0], ws.jobs[1],
+                                                                                ws.jobs[2], ws.job_counts, sr, cap, sl.job_cap,
+                                                                                regions, ws.spill, spill_threads);
+            else
+                search_kernel<false><<<ws.persistent_blocks, kBlock, 0, stream>>>(scene.meshes, scene.mesh0, ws.jobs[0], ws.jobs[1],
+                                                                                 ws.jobs[2], ws.job_counts, sr, cap, sl.job_cap,
+                                                                                 regions, ws.spill, spill_threads);
             if (search_events && (e = hipEventRecord(e1, stream)) != hipSuccess) return e;
         }
         // one loop over the root's children where the scene has that shape (not in the linear-scan mode,

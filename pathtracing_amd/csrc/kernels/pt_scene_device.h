@@ -186,6 +186,7 @@ struct DScene {
     // walk kernel then runs one loop over the children instead of the general resumable walk.
     uint32_t flat_root;
     DRun run;
+    DMesh mesh0; // copy of meshes[0]: scenes with one mesh hand it to the search kernel as an argument
 };
 
 // Camera::get_ray inputs with the per-task constants precomputed on the host.
