@@ -104,6 +104,8 @@ struct PtScene {
         for (int k = 0; k < 2; k++) {
             if (ws.hits[k]) (void)hipFree(ws.hits[k]);
             ws.hits[k] = nullptr;
+            if (ws.listed[k]) (void)hipFree(ws.listed[k]);
+            ws.listed[k] = nullptr;
         }
         if (ws.hit_uv_y) (void)hipFree(ws.hit_uv_y);
         ws.hit_uv_y = nullptr;
@@ -165,6 +167,8 @@ struct PtScene {
             alloc(&ws.run_res, ws.job_records * sizeof(float4));
         }
         for (uint32_t k = 0; k < result_arrays; k++) alloc(&ws.results[k], records * sizeof(float4));
+        if (result_arrays)
+            for (int q = 0; q < 2; q++) alloc(&ws.listed[q], records * sizeof(uint32_t));
         for (int k = 0; k < 2; k++) alloc(&ws.hits[k], records * sizeof(float4));
         alloc(&ws.hit_uv_y, records * sizeof(float));
         alloc(&ws.contrib, paths * 3 * sizeof(float));

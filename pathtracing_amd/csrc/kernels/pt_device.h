@@ -924,12 +924,12 @@ __device__ __forceinline__ int walk(const DScene& sc, WalkState& w, Hit& cur, bo
 // over one mesh (DScene::flat_root): one wave-uniform loop over the children, the ray and the
 // running best in registers, nothing saved or resumed.  Arithmetic and comparisons are those of
 // walk(): node_collection.rs:43-55 around sphere.rs / plane.rs / transform.rs + hierarchy/mesh.rs.
-// `res[m][index]` = the closest triangle of the scene's m-th mesh node for this ray (m below
-// `deferred`; further mesh nodes are searched here); `live_meshes`, `run` as in walk().
+// `res[m][index]` = the closest triangle of the scene's m-th mesh node for this ray where bit m of
+// `listed` is set (m below `deferred`; further mesh nodes are searched here); `live_meshes`, `run` as in walk().
 template <bool kRun>
 __device__ __forceinline__ void walk_flat(const DScene& sc, const Ray& world, float4* const* res, size_t index,
-                                          uint32_t deferred, uint32_t live_meshes, const RunLookup* run, TravStack& st,
-                                          Hit* out) {
+                                          uint32_t deferred, uint32_t listed, uint32_t live_meshes, const RunLookup* run,
+                                          TravStack& st, Hit* out) {
     ConstNodePtr nodes = const_nodes(sc);
     Hit best;
     best.hit = 0u;
@@ -983,7 +983,8 @@ __device__ __forceinline__ void walk_flat(const DScene& sc, const Ray& world, fl
                     const DMesh& mesh = sc.meshes[nd.mesh_id];
                     TravState ts;
                     if (m < deferred) {
-                        float4 r = res[m][index];
+                        float4 r = make_float4(f32_inf(), __uint_as_float(0u), __uint_as_float(0u), __uint_as_float(0xFFFFFFFFu));
+                        if ((listed >> m) & 1u) r = res[m][index];
                         ts.tbest = r.x;
                         ts.found = __float_as_uint(r.y);
                         ts.best_slot = __float_as_uint(r.z);

@@ -30,6 +30,8 @@ struct Workspace {
     uint32_t* job_counts = nullptr;
     uint64_t job_records = 0;
     float4* results[16] = {};
+    // per queue, per ray: which of the searched mesh nodes the ray has a job (and so a result) for
+    uint32_t* listed[2] = {nullptr, nullptr};
     // instance run: job slots per ray set aside for its children, per ray the head of its chain of
     // jobs (indexed like a queue), per job its result (indexed like `jobs`)
     uint32_t run_slots = 0;

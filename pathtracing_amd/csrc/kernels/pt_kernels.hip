@@ -73,7 +73,7 @@ uint32_t segment_blocks_per_cu() { return kGridBlocksPerCu; }
 // takes regions w, w + W, ...), so nothing here needs atomics:
 //   rays    this segment's rays            (source,min) (direction,path id) (multiplier,draw counter)
 //   next    rays of the next segment, appended per region, lengths in next_counts
-//   res[m]  closest triangle of the scene's m-th mesh node for each ray, indexed like
+//   res[m]  closest triangle of the scene's m-th mesh node for each ray that has a job for it, indexed like
 //           `rays`: (t, found, leaf slot, triangle index)
 struct SegmentBuffers {
     float4 *ray_a, *ray_b, *ray_c;
@@ -83,6 +83,9 @@ struct SegmentBuffers {
     float4* res[kMaxDeferred];
     float4 *hit_a, *hit_b; // the segment's hits, written by walk_kernel for bounce_kernel
     float* hit_c;
+    // per ray: bit m set = the ray has a job for the scene's m-th mesh node, i.e. res[m] will hold a result for
+    // it; clear = the ray cannot reach that mesh and nothing is stored ("no triangle" is implied)
+    uint32_t *listed, *next_listed;
     // instance run: per ray the head of its chain of jobs, the job rows that hold the chain, one result per job
     uint32_t* run_head;
     const float4* run_job_c;
@@ -110,13 +113,13 @@ typedef const __attribute__((address_space(4))) MeshTarget* ConstTargetPtr;
 // Lists the searches of `world` (queued at record `item` of the wave's region r,
 // `queued` = this lane queued a ray): per mesh node, the ray goes through the
 // transform nodes above the mesh (the arithmetic the walk kernel repeats later,
-// transform.rs:45-48); if it can reach the mesh it becomes a job, otherwise its "no
-// triangle" result is stored right here.  Wave-uniform control flow; `job_pos`
-// counts the region's jobs.
+// transform.rs:45-48); if it can reach the mesh it becomes a job.  Returns the lane's
+// mask of listed mesh nodes.  Wave-uniform control flow; `job_pos` counts the region's jobs.
 template <bool kRun>
-__device__ __forceinline__ void list_searches(const DScene& scene, const SearchList& sl, float4* const* res, bool queued,
-                                              const Ray& world, uint32_t r, uint32_t cap, uint32_t item, uint32_t& job_pos,
-                                              uint32_t& run_used, unsigned long long lane_lt) {
+__device__ __forceinline__ uint32_t list_searches(const DScene& scene, const SearchList& sl, bool queued,
+                                                  const Ray& world, uint32_t r, uint32_t cap, uint32_t item, uint32_t& job_pos,
+                                                  uint32_t& run_used, unsigned long long lane_lt) {
+    uint32_t listed = 0u; // bit m: this lane's ray got a job for mesh node m
     ConstNodePtr nodes = const_nodes(scene);
     ConstTargetPtr targets = (ConstTargetPtr)(unsigned long long)scene.targets;
     const size_t job_base = (size_t)r * sl.job_cap;
@@ -128,9 +131,7 @@ __device__ __forceinline__ void list_searches(const DScene& scene, const SearchL
             const uint32_t chain_len = targets[m].chain_len;
             for (uint32_t c = 0; c < chain_len; c++) ray = transform_ray_c(nodes[targets[m].chain[c]], ray);
             need = trav_reaches(scene.meshes[mesh_id], ray);
-            if (!need)
-                res[m][(size_t)r * cap + item] =
-                    make_float4(f32_inf(), __uint_as_float(0u), __uint_as_float(0u), __uint_as_float(0xFFFFFFFFu));
+            if (need) listed |= 1u << m;
         }
         const unsigned long long mask = __ballot(need);
         if (need) {
@@ -141,7 +142,7 @@ __device__ __forceinline__ void list_searches(const DScene& scene, const SearchL
         }
         job_pos += (uint32_t)__popcll(mask);
     }
-    if (!kRun || sl.run == 0u) return;
+    if (!kRun || sl.run == 0u) return listed;
     // The instance run: one job per child whose world-space box the ray pierces and whose mesh
     // bounds the ray reaches in the child's space.  A ray's jobs are chained through job_c.w.
     // When the region's job list is full the ray is marked and searched while walking instead.
@@ -182,6 +183,7 @@ __device__ __forceinline__ void list_searches(const DScene& scene, const SearchL
         run_used += wanted;
     }
     if (queued) sl.run_head[(size_t)r * cap + item] = head;
+    return listed;
 }
 
 // -------------------------------------------------------------- camera kernel
@@ -251,7 +253,10 @@ camera_kernel(RenderParams p, SegmentBuffers b, SearchList sl, uint32_t cap, uin
                 b.ray_b[o] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, __uint_as_float((uint32_t)slot));
                 b.ray_c[o] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng_counter));
             }
-            if (sl.count | sl.run) list_searches<kRun>(p.scene, sl, b.res, have, ray, r, cap, item, job_pos, run_used, lane_lt);
+            if (sl.count | sl.run) {
+                const uint32_t listed = list_searches<kRun>(p.scene, sl, have, ray, r, cap, item, job_pos, run_used, lane_lt);
+                if (have && sl.count) b.listed[base + item] = listed;
+            }
             out_pos += (uint32_t)__popcll(mask);
         }
         if (lane == 0u) {
@@ -313,10 +318,13 @@ walk_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions, un
             cur.uv = mk2(0, 0);
             // which of the searched mesh nodes hold a triangle for any ray of this wave
             uint32_t live = 0xFFFFFFFFu;
+            uint32_t listed = 0u; // which of them this ray has a result for
             if (!brute) {
                 const uint32_t searched = p.scene.target_count < (uint32_t)kMaxDeferred ? p.scene.target_count : (uint32_t)kMaxDeferred;
+                if (searched) listed = b.listed[base + item];
                 for (uint32_t m = 0; m < searched; m++) {
-                    const uint32_t found = __float_as_uint(b.res[m][base + item].y);
+                    uint32_t found = 0u;
+                    if ((listed >> m) & 1u) found = __float_as_uint(b.res[m][base + item].y);
                     if (__ballot(found != 0u) == 0ull) live &= ~(1u << m);
                 }
             }
@@ -329,7 +337,7 @@ walk_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions, un
                 look.run_res = b.run_res + (size_t)r * b.job_cap;
             }
             if (kFlat) {
-                walk_flat<kRun>(p.scene, ray, b.res, base + item, (uint32_t)kMaxDeferred, live, have_run ? &look : nullptr, st, &cur);
+                walk_flat<kRun>(p.scene, ray, b.res, base + item, (uint32_t)kMaxDeferred, listed, live, have_run ? &look : nullptr, st, &cur);
                 uint32_t tag = cur.hit ? (cur.material_id | (cur.hit_inside << 31)) : 0xFFFFFFFFu;
                 b.hit_a[base + item] = make_float4(cur.point.x, cur.point.y, cur.point.z, __uint_as_float(tag));
                 b.hit_b[base + item] = make_float4(cur.normal.x, cur.normal.y, cur.normal.z, cur.uv.x);
@@ -343,7 +351,8 @@ walk_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions, un
             while (walk<kRun>(p.scene, w, cur, resume, brute, st, false, live, have_run ? &look : nullptr) == kWalkMesh) {
                 const uint32_t m = const_nodes(p.scene)[__builtin_amdgcn_readfirstlane(w.i)].mesh_ordinal;
                 if (m < (uint32_t)kMaxDeferred) {
-                    float4 res = b.res[m][base + item];
+                    float4 res = make_float4(f32_inf(), __uint_as_float(0u), __uint_as_float(0u), __uint_as_float(0xFFFFFFFFu));
+                    if ((listed >> m) & 1u) res = b.res[m][base + item];
                     ts.tbest = res.x;
                     ts.found = __float_as_uint(res.y);
                     ts.best_slot = __float_as_uint(res.z);
@@ -480,8 +489,10 @@ bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList sl, u
                 b.next_b[slot] = make_float4(nray.direction.x, nray.direction.y, nray.direction.z, __uint_as_float(path));
                 b.next_c[slot] = make_float4(nmult.x, nmult.y, nmult.z, __uint_as_float(rng_counter));
             }
-            if ((sl.count | sl.run) && emit_mask != 0ull)
-                list_searches<kRun>(p.scene, sl, b.res, emit, nray, r, cap, next_item, job_pos, run_used, lane_lt);
+            if ((sl.count | sl.run) && emit_mask != 0ull) {
+                const uint32_t listed = list_searches<kRun>(p.scene, sl, emit, nray, r, cap, next_item, job_pos, run_used, lane_lt);
+                if (emit && sl.count) b.next_listed[base + next_item] = listed;
+            }
             out_pos += (uint32_t)__popcll(emit_mask);
         }
         if (lane == 0u) {
@@ -836,6 +847,7 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
     // job slots per ray for the children of the instance run (more candidates than that are searched while walking)
     const uint32_t run_slots = (!brute && scene.run.child_count != 0u) ? ws.run_slots : 0u;
     if (run_slots && (!ws.run_head || !ws.run_res)) return hipErrorInvalidValue;
+    if (searched && (!ws.listed[0] || !ws.listed[1])) return hipErrorInvalidValue;
     const uint32_t spill_threads = ws.persistent_blocks * kBlock;
     unsigned long long* rt = reinterpret_cast<unsigned long long*>(ws.ray_total);
     hipError_t e;
@@ -854,6 +866,8 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
         b.hit_a = ws.hits[0];
         b.hit_b = ws.hits[1];
         b.hit_c = ws.hit_uv_y;
+        b.listed = ws.listed[in];
+        b.next_listed = ws.listed[out];
         b.run_head = ws.run_head;
         b.run_job_c = ws.jobs[2];
         b.run_res = ws.run_res;
