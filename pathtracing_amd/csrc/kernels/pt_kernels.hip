@@ -504,6 +504,127 @@ bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList sl, u
     if (lane == 0u && listed) atomicAdd(sl.search_total, listed);
 }
 
+// ------------------------------------------------------- walk + bounce in one
+// Scenes with a flat root and no instance run: walk_flat and the bounce in one kernel, the hit
+// staying in registers (the two kernels hand each other 36 bytes per ray through memory, and the
+// bounce is bound by its memory traffic).  168 registers, three waves per SIMD; fetching the next
+// chunk's records ahead, as bounce_kernel does, costs more in spills than it hides here.  Scenes with an instance run keep the two kernels: the
+// walk reads the segment's job list while the bounce overwrites it with the next segment's.
+__global__ void __launch_bounds__(kBlock, 3)
+walk_bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList sl, uint32_t cap, uint32_t regions,
+                   float* contrib, unsigned long long* ray_total, uint32_t* spill, uint32_t spill_threads) {
+    __shared__ int32_t lds_stack[kLdsStack * kBlock];
+    const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+    const uint32_t waves = (gridDim.x * kBlock) >> 6;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    TravStack st = make_stack(lds_stack, spill, spill_threads);
+    unsigned long long traced = 0, jobs_listed = 0;
+    constexpr uint32_t kLdsMaterials = 32;
+    __shared__ DMaterial lds_materials[kLdsMaterials];
+    const uint32_t n_lds = p.scene.material_count < kLdsMaterials ? p.scene.material_count : kLdsMaterials;
+    for (uint32_t i = threadIdx.x; i < n_lds * (uint32_t)(sizeof(DMaterial) / 4); i += kBlock)
+        reinterpret_cast<uint32_t*>(lds_materials)[i] = reinterpret_cast<const uint32_t*>(p.scene.materials)[i];
+    __syncthreads();
+    const uint32_t searched = p.scene.target_count < (uint32_t)kMaxDeferred ? p.scene.target_count : (uint32_t)kMaxDeferred;
+
+    for (uint32_t r = wave; r < regions; r += waves) {
+        const size_t base = (size_t)r * cap;
+        const uint32_t n_items = b.ray_counts[r];
+        traced += n_items;
+        uint32_t out_pos = 0u, job_pos = 0u, run_used = 0u;
+        for (uint32_t first = 0; first < n_items; first += 64u) {
+            const uint32_t item = first + lane;
+            const bool active = item < n_items;
+            bool emit = false;
+            Ray nray;
+            V3 nmult = mk3(0, 0, 0);
+            uint32_t path = 0, rng_counter = 0;
+            // ---- hierarchy.trace_ray (work_group.rs:30)
+            float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
+            uint32_t listed = 0u;
+            if (active) {
+                ra = b.ray_a[base + item];
+                rb = b.ray_b[base + item];
+                rc = b.ray_c[base + item];
+                if (searched) listed = b.listed[base + item];
+            }
+            uint32_t live = 0xFFFFFFFFu;
+            for (uint32_t m = 0; m < searched; m++) {
+                uint32_t found = 0u;
+                if ((listed >> m) & 1u) found = __float_as_uint(b.res[m][base + item].y);
+                if (__ballot(found != 0u) == 0ull) live &= ~(1u << m);
+            }
+            if (active) {
+                Ray ray;
+                ray.source = mk3(ra.x, ra.y, ra.z);
+                ray.min = ra.w;
+                ray.direction = mk3(rb.x, rb.y, rb.z);
+                ray.max = kF32Max;
+                Hit cur;
+                walk_flat<false>(p.scene, ray, b.res, base + item, (uint32_t)kMaxDeferred, listed, live, nullptr, st, &cur);
+                // ---- the rest of the segment (work_group.rs:31-47)
+                path = __float_as_uint(rb.w);
+                rng_counter = __float_as_uint(rc.w);
+                V3 color = mk3(0, 0, 0);
+                bool finished = true;
+                if (cur.hit) {
+                    V3 mult = mk3(rc.x, rc.y, rc.z);
+                    uint32_t s_local = path / p.geo.npp, q = path % p.geo.npp;
+                    uint32_t x, y;
+                    bool valid;
+                    path_slot_to_pixel(p.geo, q, &x, &y, &valid);
+                    Rng rng;
+                    rng.key = stream_key(p.seed, stream_id(p.sample_first + s_local, (uint64_t)x + (uint64_t)y * p.cam.width));
+                    rng.counter = rng_counter;
+                    V3 av, dir;
+                    const DMaterial* material = cur.material_id < n_lds ? &lds_materials[cur.material_id] : &p.scene.materials[cur.material_id];
+                    bool is_color = material_get_color(*material, ray.direction, cur, rng, &av, &dir);
+                    rng_counter = rng.counter;
+                    if (is_color) {
+                        color = mult * av;
+                    } else if (depth + 1u < p.trace_depth) {
+                        nray.source = cur.point + dir * kEpsilon;
+                        nray.direction = dir;
+                        nray.min = kEpsilon;
+                        nray.max = kF32Max;
+                        nmult = mult * av;
+                        finished = false;
+                        emit = true;
+                    }
+                }
+                if (finished) {
+                    float* dst = contrib + (size_t)path * 3;
+                    dst[0] = color.x;
+                    dst[1] = color.y;
+                    dst[2] = color.z;
+                }
+            }
+            unsigned long long emit_mask = __ballot(emit);
+            const uint32_t next_item = out_pos + (uint32_t)__popcll(emit_mask & lane_lt);
+            if (emit) {
+                size_t slot = base + next_item;
+                b.next_a[slot] = make_float4(nray.source.x, nray.source.y, nray.source.z, nray.min);
+                b.next_b[slot] = make_float4(nray.direction.x, nray.direction.y, nray.direction.z, __uint_as_float(path));
+                b.next_c[slot] = make_float4(nmult.x, nmult.y, nmult.z, __uint_as_float(rng_counter));
+            }
+            if (sl.count && emit_mask != 0ull) {
+                const uint32_t next_listed = list_searches<false>(p.scene, sl, emit, nray, r, cap, next_item, job_pos, run_used, lane_lt);
+                if (emit) b.next_listed[base + next_item] = next_listed;
+            }
+            out_pos += (uint32_t)__popcll(emit_mask);
+        }
+        if (lane == 0u) {
+            b.next_counts[r] = out_pos;
+            if (sl.count) sl.job_counts[r] = job_pos;
+        }
+        jobs_listed += job_pos;
+    }
+    if (lane == 0u && traced) atomicAdd(ray_total, traced);
+    if (lane == 0u && jobs_listed) atomicAdd(sl.search_total, jobs_listed);
+}
+
 // -------------------------------------------------------------- search kernel
 struct SearchResults {
     float4* res[kMaxDeferred]; // per listed mesh node: closest triangle per ray, indexed like the ray queue
@@ -922,6 +1043,11 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
         // one loop over the root's children where the scene has that shape (not in the linear-scan mode,
         // whose searches happen inside the general walk)
         const bool flat = scene.flat_root != 0u && !brute;
+        if (flat && !with_run) {
+            walk_bounce_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, b, sl, cap, regions, ws.contrib, rt, ws.spill,
+                                                                            spill_threads);
+            continue;
+        }
         if (with_run) {
             if (flat) walk_kernel<true, true><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, b, cap, regions, rt, ws.spill, spill_threads);
             else walk_kernel<true, false><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, b, cap, regions, rt, ws.spill, spill_threads);
