@@ -12,6 +12,6 @@ timeout -s KILL 120 rocprofv3 --pmc $COUNTERS --output-format csv -d $OUT/sq -- 
 {
   echo "# rocprofv3 --pmc $COUNTERS -- python3 tools/profile_render.py 64"
   echo "# dragon stand-in 1920x1080, 64 spp, depth 8 (one batch per render: 8 launches of each trace kernel, two renders); sums over launches"
-  for k in search_kernel walk_kernel bounce_kernel camera_kernel; do echo "[$k]"; python3 tools/pmc_summary.py $OUT/sq $k; done
+  for k in search_kernel walk_bounce_kernel camera_kernel; do echo "[$k]"; python3 tools/pmc_summary.py $OUT/sq $k; done
 } > profiles/r${R}_sq_counters.txt
 cat profiles/r${R}_sq_counters.txt
