@@ -4,11 +4,12 @@
 //   camera_kernel        the batch's camera rays
 //   per path segment:    search_kernel (closest triangle per ray and mesh node; the
 //                        searches were listed by the kernel that queued the rays:
-//                        camera_kernel or the previous bounce_kernel), walk_kernel
-//                        (scene-graph walk: the segment's hit), bounce_kernel
+//                        camera_kernel or the previous bounce), then the walk
+//                        (scene-graph walk: the segment's hit) and the bounce
 //                        (material sampling; survivors go to the wave's region of
 //                        the other queue, finished paths store their colour into
-//                        the contribution buffer)
+//                        the contribution buffer) -- walk_bounce_kernel where the
+//                        scene's shape allows it, walk_kernel + bounce_kernel otherwise
 //   accumulate_kernel    per pixel, adds the batch's contributions in sample order
 // (work_group.rs:26-69 is the per-pixel loop this replaces).
 #include <hip/hip_runtime.h>
@@ -275,9 +276,8 @@ camera_kernel(RenderParams p, SegmentBuffers b, SearchList sl, uint32_t cap, uin
 //   hit_a (point.xyz, material id | hit_inside << 31; 0xFFFFFFFF = nothing hit)
 //   hit_b (normal.xyz, uv.x)      hit_c uv.y
 // Scenes with more than kMaxDeferred mesh nodes, and the linear-scan mode, search
-// the remaining meshes in place.  The walk keeps two hit records and a ray per lane
-// alive (3 waves per SIMD); everything that can run at full occupancy is left to
-// bounce_kernel.
+// the remaining meshes in place.  kFlat: the scene has a flat root (walk_flat);
+// otherwise the general resumable walk.
 // Waves per SIMD the kernel is compiled for: four without the instance-run code (128 registers:
 // the loop over a flat root's children and the general walk both fit), three with it.
 template <bool kRun, bool kFlat>
