@@ -3,7 +3,8 @@ bit: base materials with every mix of reflective / refractive / emissive shares,
 plain and textured colours in both uv modes, PBR materials over the whole roughness /
 metallic square, cameras with every bokeh shape, rotations, near planes and
 resolutions that are no multiple of anything, tiles, sample offsets and batch sizes.
-PATHTRACING_AMD_FUZZ_SEEDS sets how many cases are tried (default 40)."""
+PATHTRACING_AMD_FUZZ_SEEDS sets how many cases are tried (default 40),
+PATHTRACING_AMD_FUZZ_FIRST the first seed (default 0)."""
 import json
 import math
 import os
@@ -88,7 +89,8 @@ def fuzz_root(tmp_path_factory):
     return root
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("PATHTRACING_AMD_FUZZ_SEEDS", "40"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PATHTRACING_AMD_FUZZ_FIRST", "0")),
+                                        int(os.environ.get("PATHTRACING_AMD_FUZZ_FIRST", "0")) + int(os.environ.get("PATHTRACING_AMD_FUZZ_SEEDS", "40"))))
 def test_random_materials_cameras_options(oracle, fuzz_root, seed):
     rnd = np.random.default_rng(5000 + seed)
     for k in range(N_MATERIALS):

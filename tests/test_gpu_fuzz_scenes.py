@@ -3,7 +3,8 @@ secondary rays and a small render, bit for bit.  The generator covers what the
 hand-written scenes do not combine: roots that are not collections, empty and nested
 collections, chains of transforms (unequal scale factors, mirrors), kd_tree nodes
 with and without a usable file, several meshes, runs of instances between other
-children.  PATHTRACING_AMD_FUZZ_SEEDS sets how many scenes are tried (default 40)."""
+children.  PATHTRACING_AMD_FUZZ_SEEDS sets how many scenes are tried (default 40),
+PATHTRACING_AMD_FUZZ_FIRST the first seed (default 0)."""
 import json
 import math
 import os
@@ -124,7 +125,8 @@ def fuzz_root(tmp_path_factory):
     return root
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("PATHTRACING_AMD_FUZZ_SEEDS", "40"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PATHTRACING_AMD_FUZZ_FIRST", "0")),
+                                        int(os.environ.get("PATHTRACING_AMD_FUZZ_FIRST", "0")) + int(os.environ.get("PATHTRACING_AMD_FUZZ_SEEDS", "40"))))
 def test_random_scene_graph(oracle, fuzz_root, seed):
     with open(os.path.join(fuzz_root, "fuzz.json"), "w") as f:
         json.dump(Generator(1000 + seed).scene(), f)
