@@ -18,6 +18,9 @@ pub const PT_ABI_VERSION: u32 = 1;
 pub const PT_NO_INDEX: u32 = 0xFFFF_FFFF;
 pub const PT_FLAG_BRUTE_FORCE: u32 = 1;
 pub const PT_FLAG_PROFILE: u32 = 2;
+pub const PT_FLAG_WAVEFRONT: u32 = 4;
+pub const PT_FLAG_WAVEFRONT_SPLIT: u32 = 8;
+pub const PT_FLAG_SINGLE_STREAM: u32 = 16;
 
 /// `PtStatus`
 pub type PtStatus = c_int;
@@ -196,6 +199,20 @@ pub struct PtRenderOpts {
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
+pub struct PtSceneInfo {
+    pub mesh_count: u32,
+    pub trees_offered: u32,
+    pub trees_adopted: u32,
+    pub trees_built: u32,
+    pub instance_run_children: u32,
+    pub triangle_count: u64,
+    pub bvh_bytes: u64,
+    pub build_ms: f64,
+    pub setup_ms: f64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
 pub struct PtRenderStats {
     pub rays: u64,
     pub paths: u64,
@@ -240,6 +257,8 @@ extern "C" {
 
     pub fn pt_scene_create(desc: *const PtSceneDesc, device: c_int, out_scene: *mut *mut PtScene) -> PtStatus;
     pub fn pt_scene_destroy(scene: *mut PtScene);
+    pub fn pt_scene_info(scene: *const PtScene, out_info: *mut PtSceneInfo) -> PtStatus;
+    pub fn pt_device_release_workspace(device: c_int) -> PtStatus;
 
     pub fn pt_render(
         scene: *mut PtScene,
@@ -296,6 +315,7 @@ extern "C" {
     pub fn pt_host_scene_load(root_dir: *const c_char, scene_path: *const c_char, out: *mut *mut PtHostScene) -> PtStatus;
     pub fn pt_host_scene_desc(scene: *const PtHostScene) -> *const PtSceneDesc;
     pub fn pt_host_scene_destroy(scene: *mut PtHostScene);
+    pub fn pt_host_scene_cache_trees(scene: *mut PtHostScene, root_dir: *const c_char, out_written: *mut u32) -> PtStatus;
     pub fn pt_render_task_parse(
         json_text: *const c_char,
         out_task: *mut PtRenderTask,

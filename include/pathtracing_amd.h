@@ -166,6 +166,32 @@ typedef struct PtScene PtScene; /* opaque: device-resident scene */
 PtStatus pt_scene_create(const PtSceneDesc* desc, int device, PtScene** out_scene);
 void pt_scene_destroy(PtScene* scene);
 
+/* What pt_scene_create did with the scene's meshes.  A kd_tree node directly above a mesh
+ * node offers its .tree blob to that mesh (kd_tree.rs:12-51 names the file; loading it is
+ * todo!() upstream, scene/mod.rs:94-96): a blob that is well formed for exactly this
+ * geometry is adopted and the build is skipped, any other blob (empty, stale, corrupt) is
+ * ignored and the structure is built. */
+typedef struct PtSceneInfo {
+    uint32_t mesh_count;
+    uint32_t trees_offered; /* meshes a non-empty .tree blob was offered for                 */
+    uint32_t trees_adopted; /* ... whose blob was adopted: the GPU searches the file's tree   */
+    uint32_t trees_built;   /* meshes whose structure was built by pt_scene_create            */
+    uint32_t instance_run_children; /* children of the root collection taken as one instance run */
+    uint64_t triangle_count; /* over all meshes                                               */
+    uint64_t bvh_bytes;      /* device bytes of nodes + leaf triangles of all meshes          */
+    double build_ms;         /* host time spent building (not adopting) structures            */
+    double setup_ms;         /* the whole of pt_scene_create                                  */
+} PtSceneInfo;
+PtStatus pt_scene_info(const PtScene* scene, PtSceneInfo* out_info);
+
+/* The queues of the wavefront pipeline belong to the device, not to a scene: all scenes of
+ * a device render through the same workspace (two when a render keeps two batches in
+ * flight), sized by the largest demand so far.  Calls on any scene and any stream of one
+ * device are ordered on the GPU by events, so a PtScene may be used from several streams
+ * and threads; renders of one device do not overlap each other.  This frees that memory
+ * (it is allocated again on demand); it waits for the device's queued renders first. */
+PtStatus pt_device_release_workspace(int device);
+
 /* ---------------------------------------------------------- the render task */
 
 typedef enum PtBokehShape { PT_BOKEH_POINT = 0, PT_BOKEH_CIRCLE = 1, PT_BOKEH_SQUARE = 2 } PtBokehShape;
@@ -192,6 +218,12 @@ typedef struct PtRenderTask {
 #define PT_FLAG_BRUTE_FORCE 1u /* scan every triangle like mesh/mod.rs:57-62 (no BVH) */
 #define PT_FLAG_PROFILE 2u     /* time every launch of the BVH search kernel with events on the
                                   render stream (fills PtRenderStats.search_kernel_*); slower  */
+#define PT_FLAG_WAVEFRONT 4u   /* pt_trace_closest: take the rays through the kernels a render
+                                  uses (queue regions, listed searches, search kernel, walk)
+                                  instead of one thread per ray; rays must have max = f32::MAX */
+#define PT_FLAG_WAVEFRONT_SPLIT 8u /* the same, with the separate walk kernel even where a
+                                  render would use the fused walk + bounce kernel              */
+#define PT_FLAG_SINGLE_STREAM 16u /* render: never keep two batches in flight                  */
 
 /* Knobs the reference does not have.  A NULL pointer means all zero. */
 typedef struct PtRenderOpts {
@@ -226,7 +258,9 @@ PtStatus pt_render(PtScene* scene, const PtRenderTask* task, const PtRenderOpts*
  * resolution_y * 3 floats, camera-space layout: pixel (x,y) at (x + y*W)*3, y
  * up) receives  d_accum += sum over this call's samples; nothing is normalised
  * or flipped.  `stream` is a hipStream_t (NULL: the default stream); the call
- * returns after enqueueing unless stats != NULL (then it synchronises). */
+ * returns after enqueueing unless stats != NULL (then it synchronises).  A render
+ * of more than one batch traces every other batch on a stream of the library's
+ * own; all of it is ordered before whatever is queued on `stream` afterwards. */
 PtStatus pt_render_accumulate_device(PtScene* scene, const PtRenderTask* task,
                                      const PtRenderOpts* opts, float* d_accum, void* stream,
                                      PtRenderStats* stats);
@@ -250,7 +284,8 @@ typedef struct PtHit {
     PtVec2 uv;
 } PtHit;
 
-/* scene.hierarchy.trace_ray(ray) for n rays (host arrays). */
+/* scene.hierarchy.trace_ray(ray) for n rays (host arrays).  flags: PT_FLAG_BRUTE_FORCE,
+ * PT_FLAG_WAVEFRONT, PT_FLAG_WAVEFRONT_SPLIT. */
 PtStatus pt_trace_closest(PtScene* scene, const PtRay* rays, size_t n, uint32_t flags,
                           PtHit* out_hits);
 
@@ -278,6 +313,15 @@ typedef struct PtHostScene PtHostScene; /* opaque: parsed scene files in host me
 PtStatus pt_host_scene_load(const char* root_dir, const char* scene_path, PtHostScene** out);
 const PtSceneDesc* pt_host_scene_desc(const PtHostScene* scene);
 void pt_host_scene_destroy(PtHostScene* scene);
+
+/* The write side of the .tree cache: for every kd_tree node directly above a mesh node
+ * whose .tree file is missing, empty or not valid for the mesh, builds the mesh's
+ * acceleration structure, writes it to `root_dir` + "/" + the node's path (through a
+ * temporary file and a rename) and puts it into the loaded scene, so that this and every
+ * later pt_scene_create of the scene adopts it instead of building.  out_written (may be
+ * NULL) receives the number of files written.  The reference has no counterpart: its
+ * loader for this resource type is todo!() (scene/mod.rs:94-96). */
+PtStatus pt_host_scene_cache_trees(PtHostScene* scene, const char* root_dir, uint32_t* out_written);
 
 /* Parses a render task (RenderTaskUninit or RenderTask JSON text,
  * api/render_task.rs:5-29).  scene_path_buf receives the "scene" string. */

@@ -17,6 +17,9 @@ PT_OK = 0
 PT_NO_INDEX = 0xFFFFFFFF
 PT_FLAG_BRUTE_FORCE = 1
 PT_FLAG_PROFILE = 2
+PT_FLAG_WAVEFRONT = 4
+PT_FLAG_WAVEFRONT_SPLIT = 8
+PT_FLAG_SINGLE_STREAM = 16
 
 NODE_COLLECTION, NODE_TRANSFORM, NODE_MESH, NODE_SPHERE, NODE_PLANE, NODE_KD_TREE = range(6)
 MATERIAL_BASE, MATERIAL_PBR = 0, 1
@@ -122,6 +125,20 @@ class PtSceneDesc(C.Structure):
     ]
 
 
+class PtSceneInfo(C.Structure):
+    _fields_ = [
+        ("mesh_count", C.c_uint32),
+        ("trees_offered", C.c_uint32),
+        ("trees_adopted", C.c_uint32),
+        ("trees_built", C.c_uint32),
+        ("instance_run_children", C.c_uint32),
+        ("triangle_count", C.c_uint64),
+        ("bvh_bytes", C.c_uint64),
+        ("build_ms", C.c_double),
+        ("setup_ms", C.c_double),
+    ]
+
+
 class PtCamera(C.Structure):
     _fields_ = [
         ("resolution_x", C.c_uint64),
@@ -186,6 +203,8 @@ SYMBOLS = {
     "pt_abi_version": (C.c_uint32, []),
     "pt_scene_create": (C.c_int, [C.POINTER(PtSceneDesc), C.c_int, C.POINTER(_VOIDP)]),
     "pt_scene_destroy": (None, [_VOIDP]),
+    "pt_scene_info": (C.c_int, [_VOIDP, C.POINTER(PtSceneInfo)]),
+    "pt_device_release_workspace": (C.c_int, [C.c_int]),
     "pt_render": (C.c_int, [_VOIDP, C.POINTER(PtRenderTask), C.POINTER(PtRenderOpts), _VOIDP, C.POINTER(PtRenderStats)]),
     "pt_render_accumulate_device": (
         C.c_int,
@@ -198,6 +217,7 @@ SYMBOLS = {
     "pt_host_scene_load": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(_VOIDP)]),
     "pt_host_scene_desc": (C.POINTER(PtSceneDesc), [_VOIDP]),
     "pt_host_scene_destroy": (None, [_VOIDP]),
+    "pt_host_scene_cache_trees": (C.c_int, [_VOIDP, C.c_char_p, C.POINTER(C.c_uint32)]),
     "pt_render_task_parse": (C.c_int, [C.c_char_p, C.POINTER(PtRenderTask), C.c_char_p, C.c_size_t]),
     "pt_tree_build": (C.c_int, [C.POINTER(PtMeshDesc), C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]),
     "pt_buffer_free": (None, [C.POINTER(C.c_uint8)]),

@@ -3,11 +3,14 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -63,87 +66,137 @@ struct DeviceGuard {
 
 } // namespace
 
-struct PtScene {
+// ---- per-device workspaces -----------------------------------------------------
+// The queues, job lists, result arrays and spill columns of the wavefront pipeline
+// belong to the device, not to a scene: every PtScene of a device renders through the
+// same (at most two) workspaces, so a worker that caches several scenes
+// (worker/src/lib.rs:32-43) pays for them once.  One launch sequence uses a workspace
+// at a time: `last_use` is recorded behind the last kernel that touches it, and the
+// stream of the next user waits for that event, whichever scene and stream it is.
+// `mu` serialises the host side (sizing and enqueueing), so calls may come from
+// several threads.  A DeviceState lives until the process ends
+// (pt_device_release_workspace frees its device memory earlier).
+struct DeviceState {
     int device = 0;
-    ptk::DScene d{};
-    std::vector<void*> allocs;
-    ptk::Workspace ws;
-    uint64_t bvh_bytes = 0;
-    uint32_t node_count = 0;
-    std::vector<ptk::MeshTarget> targets; // the mesh nodes outside the instance run = BVH searches every ray needs per segment
-    std::vector<uint32_t> mesh_tri_count;
+    std::mutex mu;
+    ptk::Workspace ws[2];
+    hipEvent_t last_use[2] = {nullptr, nullptr};
+    bool used[2] = {false, false};
+    hipStream_t side = nullptr;      // every other batch of a render that keeps two batches in flight
+    hipEvent_t fork = nullptr;       // the caller's stream at the start of such a render
+    hipEvent_t side_done = nullptr;  // a batch traced on `side`
+    hipEvent_t accumulated = nullptr; // ... and added to the image on the caller's stream
+};
 
-    void* dev_alloc(size_t bytes) {
-        void* p = nullptr;
-        hip_check(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc");
-        allocs.push_back(p);
-        return p;
+namespace {
+
+DeviceState& device_state(int device) {
+    static std::mutex registry_mu;
+    static std::map<int, DeviceState*>* registry = new std::map<int, DeviceState*>(); // never destroyed: the HIP
+    std::lock_guard<std::mutex> lock(registry_mu);                                     // runtime may be gone by then
+    auto it = registry->find(device);
+    if (it != registry->end()) return *it->second;
+    DeviceState* ds = new DeviceState();
+    ds->device = device;
+    (*registry)[device] = ds;
+    return *ds;
+}
+
+// The host waits until nothing queued on the device uses workspace k any more.
+void wait_idle(DeviceState& ds, int k) {
+    if (ds.used[k]) hip_check(hipEventSynchronize(ds.last_use[k]), "hipEventSynchronize");
+    ds.used[k] = false;
+}
+
+// Whatever is queued on `stream` from here on runs after the last use of workspace k.
+void stream_acquire(DeviceState& ds, int k, hipStream_t stream) {
+    if (ds.used[k]) hip_check(hipStreamWaitEvent(stream, ds.last_use[k], 0), "hipStreamWaitEvent");
+}
+
+// What has been queued on `stream` so far is the last use of workspace k.
+void stream_release(DeviceState& ds, int k, hipStream_t stream) {
+    if (!ds.last_use[k]) hip_check(hipEventCreateWithFlags(&ds.last_use[k], hipEventDisableTiming), "hipEventCreate");
+    hip_check(hipEventRecord(ds.last_use[k], stream), "hipEventRecord");
+    ds.used[k] = true;
+}
+
+template <class T> void free_array(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+void free_workspace(ptk::Workspace& ws) {
+    for (int q = 0; q < 2; q++)
+        for (int k = 0; k < 3; k++) free_array(ws.queue[q][k]);
+    for (int k = 0; k < 3; k++) free_array(ws.jobs[k]);
+    for (int k = 0; k < ptk::kMaxDeferred; k++) free_array(ws.results[k]);
+    for (int k = 0; k < 2; k++) {
+        free_array(ws.hits[k]);
+        free_array(ws.listed[k]);
     }
-    template <class T> T* upload(const std::vector<T>& v) {
-        T* p = static_cast<T*>(dev_alloc(v.size() * sizeof(T)));
-        if (!v.empty()) hip_check(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy H2D");
-        return p;
-    }
-    void free_workspace() {
-        for (int q = 0; q < 2; q++)
-            for (int k = 0; k < 3; k++)
-                if (ws.queue[q][k]) {
-                    (void)hipFree(ws.queue[q][k]);
-                    ws.queue[q][k] = nullptr;
-                }
-        for (int k = 0; k < 3; k++)
-            if (ws.jobs[k]) {
-                (void)hipFree(ws.jobs[k]);
-                ws.jobs[k] = nullptr;
-            }
-        for (int k = 0; k < ptk::kMaxDeferred; k++)
-            if (ws.results[k]) {
-                (void)hipFree(ws.results[k]);
-                ws.results[k] = nullptr;
-            }
-        for (int k = 0; k < 2; k++) {
-            if (ws.hits[k]) (void)hipFree(ws.hits[k]);
-            ws.hits[k] = nullptr;
-            if (ws.listed[k]) (void)hipFree(ws.listed[k]);
-            ws.listed[k] = nullptr;
-        }
-        if (ws.hit_uv_y) (void)hipFree(ws.hit_uv_y);
-        ws.hit_uv_y = nullptr;
-        if (ws.contrib) (void)hipFree(ws.contrib);
-        ws.contrib = nullptr;
-        if (ws.run_head) (void)hipFree(ws.run_head);
-        ws.run_head = nullptr;
-        if (ws.run_res) (void)hipFree(ws.run_res);
-        ws.run_res = nullptr;
-        ws.capacity_paths = 0;
-        ws.contrib_paths = 0;
-        ws.job_records = 0;
-    }
-    // Fixed state of the trace kernels: the spill columns and per-wave queue
-    // counters of the persistent grid (4 blocks of 256 threads per compute unit).
-    void ensure_trace_state() {
-        if (ws.spill) return;
-        hipDeviceProp_t prop;
-        hip_check(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
-        uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
-        ws.persistent_blocks = cus * ptk::segment_blocks_per_cu();
-        size_t bytes = (size_t)ws.persistent_blocks * ptk::kTraceBlock * ptk::spill_dwords_per_thread() * sizeof(uint32_t);
+    free_array(ws.hit_uv_y);
+    free_array(ws.contrib);
+    free_array(ws.run_head);
+    free_array(ws.run_res);
+    ws.capacity_paths = 0;
+    ws.contrib_paths = 0;
+    ws.job_records = 0;
+    ws.result_arrays = 0;
+}
+
+void free_trace_state(ptk::Workspace& ws) {
+    for (int q = 0; q < 2; q++) free_array(ws.wave_counts[q]);
+    free_array(ws.job_counts);
+    free_array(ws.ray_total);
+    free_array(ws.spill);
+    ws.persistent_blocks = 0;
+}
+
+// Fixed state of the trace kernels: the spill columns and per-wave queue counters of
+// the persistent grid (segment_blocks_per_cu() blocks of 256 threads per compute
+// unit).  Either all of it exists afterwards or none.
+void ensure_trace_state(DeviceState& ds, int k) {
+    ptk::Workspace& ws = ds.ws[k];
+    if (ws.spill && ws.wave_counts[0] && ws.wave_counts[1] && ws.job_counts && ws.ray_total && ws.persistent_blocks) return;
+    free_trace_state(ws);
+    hipDeviceProp_t prop;
+    hip_check(hipGetDeviceProperties(&prop, ds.device), "hipGetDeviceProperties");
+    uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
+    uint32_t blocks = cus * ptk::segment_blocks_per_cu();
+    size_t bytes = (size_t)blocks * ptk::kTraceBlock * ptk::spill_dwords_per_thread() * sizeof(uint32_t);
+    size_t waves = (size_t)blocks * (ptk::kTraceBlock / 64);
+    try {
         hip_check(hipMalloc(reinterpret_cast<void**>(&ws.spill), bytes), "hipMalloc spill");
-        size_t waves = (size_t)ws.persistent_blocks * (ptk::kTraceBlock / 64);
         for (int q = 0; q < 2; q++)
             hip_check(hipMalloc(reinterpret_cast<void**>(&ws.wave_counts[q]), waves * sizeof(uint32_t)), "hipMalloc counts");
         hip_check(hipMalloc(reinterpret_cast<void**>(&ws.job_counts), waves * sizeof(uint32_t)), "hipMalloc counts");
         hip_check(hipMalloc(reinterpret_cast<void**>(&ws.ray_total), 2 * sizeof(uint64_t)), "hipMalloc ray_total");
+    } catch (...) {
+        free_trace_state(ws);
+        throw;
     }
-    // Queues, results and contributions for batches of `samples` samples of nbx x nby pixel blocks.
-    // False: the device has not that much memory left (nothing is held then).
-    bool ensure_workspace(uint32_t nbx, uint32_t nby, uint32_t samples) {
-        ensure_trace_state();
-        uint64_t paths = (uint64_t)nbx * nby * 64 * samples;
-        uint32_t waves = ws.persistent_blocks * (ptk::kTraceBlock / 64);
-        uint64_t records = (uint64_t)ptk::queue_region_capacity(nbx, nby, samples, waves) * waves;
-        if (records <= ws.capacity_paths && paths <= ws.contrib_paths) return true;
-        free_workspace();
+    ws.persistent_blocks = blocks;
+}
+
+// Queues of `records` records (all regions together), contributions of `paths` paths, job lists and
+// result arrays for `result_arrays` mesh nodes searched ahead of the walk and `run_slots` job slots per
+// ray for an instance run.  False: the device has not that much memory left (the workspace then holds
+// nothing).  A workspace that is too small is replaced by one that covers the old and the new
+// demand, so that scenes taking turns do not reallocate on every call.
+bool ensure_workspace(DeviceState& ds, int k, uint64_t records, uint64_t paths, uint32_t result_arrays, uint32_t run_slots) {
+    ensure_trace_state(ds, k);
+    ptk::Workspace& ws = ds.ws[k];
+    uint64_t job_records = records * (result_arrays + run_slots);
+    const bool want_run = run_slots != 0;
+    if (records <= ws.capacity_paths && paths <= ws.contrib_paths && job_records <= ws.job_records &&
+        result_arrays <= ws.result_arrays && (!want_run || (ws.run_head && ws.run_res)))
+        return true;
+    wait_idle(ds, k);
+    const uint64_t old_records = ws.capacity_paths, old_paths = ws.contrib_paths, old_jobs = ws.job_records;
+    const uint32_t old_results = ws.result_arrays;
+    const bool old_run = ws.run_head != nullptr;
+    free_workspace(ws);
+    auto attempt = [&](uint64_t rec, uint64_t pth, uint64_t jobs, uint32_t res, bool run) {
         bool ok = true;
         auto alloc = [&](auto** p, uint64_t bytes) {
             if (!ok) return;
@@ -157,36 +210,68 @@ struct PtScene {
             hip_check(e, "hipMalloc workspace");
         };
         for (int q = 0; q < 2; q++)
-            for (int k = 0; k < 3; k++) alloc(&ws.queue[q][k], records * sizeof(float4));
-        uint32_t result_arrays = std::min<uint32_t>((uint32_t)targets.size(), (uint32_t)ptk::kMaxDeferred);
-        ws.job_records = records * (result_arrays + ws.run_slots);
-        if (ws.job_records)
-            for (int k = 0; k < 3; k++) alloc(&ws.jobs[k], ws.job_records * sizeof(float4));
-        if (ws.run_slots) {
-            alloc(&ws.run_head, records * sizeof(uint32_t));
-            alloc(&ws.run_res, ws.job_records * sizeof(float4));
+            for (int c = 0; c < 3; c++) alloc(&ws.queue[q][c], rec * sizeof(float4));
+        if (jobs)
+            for (int c = 0; c < 3; c++) alloc(&ws.jobs[c], jobs * sizeof(float4));
+        if (run) {
+            alloc(&ws.run_head, rec * sizeof(uint32_t));
+            alloc(&ws.run_res, jobs * sizeof(float4));
         }
-        for (uint32_t k = 0; k < result_arrays; k++) alloc(&ws.results[k], records * sizeof(float4));
-        if (result_arrays)
-            for (int q = 0; q < 2; q++) alloc(&ws.listed[q], records * sizeof(uint32_t));
-        for (int k = 0; k < 2; k++) alloc(&ws.hits[k], records * sizeof(float4));
-        alloc(&ws.hit_uv_y, records * sizeof(float));
-        alloc(&ws.contrib, paths * 3 * sizeof(float));
+        for (uint32_t m = 0; m < res; m++) alloc(&ws.results[m], rec * sizeof(float4));
+        if (res)
+            for (int q = 0; q < 2; q++) alloc(&ws.listed[q], rec * sizeof(uint32_t));
+        for (int c = 0; c < 2; c++) alloc(&ws.hits[c], rec * sizeof(float4));
+        alloc(&ws.hit_uv_y, rec * sizeof(float));
+        alloc(&ws.contrib, pth * 3 * sizeof(float));
         if (!ok) {
-            free_workspace();
+            free_workspace(ws);
             return false;
         }
-        ws.capacity_paths = records;
-        ws.contrib_paths = paths;
+        ws.capacity_paths = rec;
+        ws.contrib_paths = pth;
+        ws.job_records = jobs;
+        ws.result_arrays = res;
         return true;
+    };
+    const uint64_t big_rec = std::max(records, old_records), big_paths = std::max(paths, old_paths);
+    const uint32_t big_res = std::max(result_arrays, old_results);
+    const uint64_t big_jobs = std::max({job_records, old_jobs, big_rec * (uint64_t)(result_arrays + run_slots)});
+    const bool grown = big_rec != records || big_paths != paths || big_res != result_arrays || big_jobs != job_records ||
+                       (old_run && !want_run);
+    if (grown && attempt(big_rec, big_paths, big_jobs, big_res, want_run || old_run)) return true;
+    return attempt(records, paths, job_records, result_arrays, want_run);
+}
+
+} // namespace
+
+// Job slots per ray set aside for the children of an instance run.  A ray of a grid of instances
+// pierces a handful of boxes; regions that run out search the rest while walking.
+constexpr uint32_t kRunSlotsPerRay = 8;
+
+struct PtScene {
+    int device = 0;
+    ptk::DScene d{};
+    std::vector<void*> allocs;
+    uint64_t bvh_bytes = 0;
+    uint32_t node_count = 0;
+    std::vector<ptk::MeshTarget> targets; // the mesh nodes outside the instance run = BVH searches every ray needs per segment
+    std::vector<uint32_t> mesh_tri_count;
+    uint32_t run_slots = 0; // job slots per ray for the children of the instance run (0: no run)
+    PtSceneInfo info{};
+
+    uint32_t result_arrays() const { return std::min<uint32_t>((uint32_t)targets.size(), (uint32_t)ptk::kMaxDeferred); }
+    void* dev_alloc(size_t bytes) {
+        void* p = nullptr;
+        hip_check(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc");
+        allocs.push_back(p);
+        return p;
+    }
+    template <class T> T* upload(const std::vector<T>& v) {
+        T* p = static_cast<T*>(dev_alloc(v.size() * sizeof(T)));
+        if (!v.empty()) hip_check(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy H2D");
+        return p;
     }
     ~PtScene() {
-        free_workspace();
-        for (int q = 0; q < 2; q++)
-            if (ws.wave_counts[q]) (void)hipFree(ws.wave_counts[q]);
-        if (ws.job_counts) (void)hipFree(ws.job_counts);
-        if (ws.ray_total) (void)hipFree(ws.ray_total);
-        if (ws.spill) (void)hipFree(ws.spill);
         for (void* p : allocs) (void)hipFree(p);
     }
 };
@@ -295,10 +380,6 @@ uint32_t single_mesh_below(const std::vector<ptk::DNode>& nodes, uint32_t transf
     if (j < nodes.size() && nodes[j].type == PT_NODE_MESH && nodes[transform].end == j + 1) return j;
     return 0xFFFFFFFFu;
 }
-
-// Job slots per ray set aside for the children of an instance run.  A ray of a grid of instances
-// pierces a handful of boxes; regions that run out search the rest while walking.
-constexpr uint32_t kRunSlotsPerRay = 8;
 
 struct InstanceRun {
     uint32_t first_node = 0xFFFFFFFFu, end_node = 0xFFFFFFFFu;
@@ -490,10 +571,34 @@ void build_mesh(PtScene& s, const PtMeshDesc& m, const PtTreeBlob* blob, ptk::DM
     if (m.triangle_count && !m.positions) throw Error(PT_ERR_INVALID_ARGUMENT, "mesh without positions");
     if (m.triangle_count >= (1ull << 28)) throw Error(PT_ERR_UNSUPPORTED, "mesh has too many triangles");
     const uint64_t n = m.triangle_count;
+    // A .tree blob is adopted only if it describes exactly this mesh and the kernels can search it;
+    // anything else (empty, stale, corrupt, too deep) is ignored and the tree is built here.
     pt::BuiltBvh bvh;
+    pt::WideBvh wide;
     bool adopted = false;
-    if (blob && blob->size && blob->data) adopted = pt::deserialize_tree(blob->data, blob->size, m.positions, n, &bvh);
-    if (!adopted) bvh = pt::build_bvh(m.positions, n, 4); // leaves of 2..4 triangles render equally fast, 1 and 6+ slower
+    const bool offered = blob && blob->size && blob->data;
+    if (offered) {
+        try {
+            if (pt::deserialize_tree(blob->data, blob->size, m.positions, n, &bvh)) {
+                wide = pt::widen_bvh(bvh);
+                adopted = wide.max_stack <= ptk::traversal_stack_capacity();
+            }
+        } catch (const Error&) {
+            adopted = false;
+        }
+    }
+    if (!adopted) {
+        auto t0 = std::chrono::steady_clock::now();
+        bvh = pt::build_bvh(m.positions, n, 4); // leaves of 2..4 triangles render equally fast, 1 and 6+ slower
+        wide = pt::widen_bvh(bvh);
+        s.info.build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (wide.max_stack > ptk::traversal_stack_capacity())
+            throw Error(PT_ERR_UNSUPPORTED, "BVH needs a deeper traversal stack than the kernels keep");
+    }
+    s.info.trees_offered += offered ? 1u : 0u;
+    s.info.trees_adopted += adopted ? 1u : 0u;
+    s.info.trees_built += adopted ? 0u : 1u;
+    s.info.triangle_count += n;
 
     std::vector<ptk::LeafTri> leaf(n), orig(n);
     std::vector<ptk::ShadeTri> shade(n);
@@ -524,9 +629,6 @@ void build_mesh(PtScene& s, const PtMeshDesc& m, const PtTreeBlob* blob, ptk::DM
     }
     for (uint64_t k = 0; k < n; k++) leaf[k] = orig[bvh.order[k]];
 
-    pt::WideBvh wide = pt::widen_bvh(bvh);
-    if (wide.max_stack > ptk::traversal_stack_capacity())
-        throw Error(PT_ERR_UNSUPPORTED, "BVH needs a deeper traversal stack than the kernels keep");
     out->nodes = s.upload(wide.nodes);
     out->tris = s.upload(leaf);
     out->tris_orig = s.upload(orig);
@@ -594,6 +696,12 @@ struct PtFrame {
 
 namespace {
 
+// PATHTRACING_AMD_STREAMS=1: renders never keep two batches in flight.
+bool two_streams_allowed() {
+    const char* v = getenv("PATHTRACING_AMD_STREAMS");
+    return !(v && atoi(v) == 1);
+}
+
 void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderOpts* opts_in, float* d_accum,
                        hipStream_t stream, PtRenderStats* stats) {
     if (!scene || !task || !d_accum) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
@@ -611,15 +719,22 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
         w = std::min(o.tile_w, cam.width - x0);
         h = std::min(o.tile_h, cam.height - y0);
     }
+    DeviceState& ds = device_state(scene->device);
+    std::lock_guard<std::mutex> lock(ds.mu);
+    const bool brute = (o.flags & PT_FLAG_BRUTE_FORCE) != 0;
+    const bool profile = stats && (o.flags & PT_FLAG_PROFILE) != 0;
     // Path slots per batch.  Bigger batches are faster (fewer launches whose last waves run alone, more
     // samples of a pixel block next to each other); a slot costs about 210 bytes of queues, nine times
     // the job records on top for scenes with an instance run.  The default is halved until it fits.
-    uint64_t budget = o.paths_per_batch ? o.paths_per_batch : ((scene->ws.run_slots ? 32ull : 128ull) << 20);
+    uint64_t budget = o.paths_per_batch ? o.paths_per_batch : ((scene->run_slots ? 32ull : 128ull) << 20);
     if (budget < 64) budget = 64;
-    uint32_t nbx = (w + 7) / 8;
-    uint64_t slots_per_block_row = (uint64_t)nbx * 64;
-    uint32_t total_block_rows = (h + 7) / 8;
+    const uint32_t nbx = (w + 7) / 8;
+    const uint64_t slots_per_block_row = (uint64_t)nbx * 64;
+    const uint32_t total_block_rows = (h + 7) / 8;
     uint32_t band_block_rows = 0, samples_per_batch = 0;
+    bool two = false; // two batches in flight: the second workspace on the side stream
+    ensure_trace_state(ds, 0);
+    const uint32_t waves = ds.ws[0].persistent_blocks * (ptk::kTraceBlock / 64);
     for (;;) {
         // bands of whole 8-pixel rows such that one sample of a band fits the budget
         band_block_rows = (uint32_t)std::min<uint64_t>(total_block_rows, std::max<uint64_t>(1, budget / slots_per_block_row));
@@ -627,29 +742,66 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
         samples_per_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / band_slots, task->iterations ? task->iterations : 1));
         // a batch indexes its path slots with 32 bits
         while ((uint64_t)samples_per_batch * band_slots > 0xFFFFFFFFull && samples_per_batch > 1) samples_per_batch /= 2;
-        if (scene->ensure_workspace(nbx, band_block_rows, samples_per_batch)) break;
+        const uint64_t n_batches = (uint64_t)((total_block_rows + band_block_rows - 1) / band_block_rows) *
+                                   ((task->iterations + samples_per_batch - 1) / samples_per_batch);
+        two = n_batches >= 2 && !profile && !(o.flags & PT_FLAG_SINGLE_STREAM) && two_streams_allowed();
+        const uint64_t records = (uint64_t)ptk::queue_region_capacity(nbx, band_block_rows, samples_per_batch, waves) * waves;
+        const uint64_t paths = band_slots * samples_per_batch;
+        bool ok = ensure_workspace(ds, 0, records, paths, scene->result_arrays(), scene->run_slots);
+        if (ok && two) {
+            ok = ensure_workspace(ds, 1, records, paths, scene->result_arrays(), scene->run_slots);
+            if (!ok) { // one workspace fits, two do not: render with one
+                two = false;
+                ok = true;
+            }
+        }
+        if (ok) break;
         if (o.paths_per_batch || budget <= (1ull << 20))
             throw Error(PT_ERR_DEVICE, "out of device memory for the render's queues (paths_per_batch " + std::to_string(budget) + ")");
         budget /= 2;
     }
-
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (stats) {
-        hip_check(hipEventCreate(&ev0), "hipEventCreate");
-        hip_check(hipEventCreate(&ev1), "hipEventCreate");
-        hip_check(hipMemsetAsync(scene->ws.ray_total, 0, 2 * sizeof(uint64_t), stream), "hipMemsetAsync");
-        hip_check(hipEventRecord(ev0, stream), "hipEventRecord");
+    if (two) {
+        if (!ds.side) hip_check(hipStreamCreateWithFlags(&ds.side, hipStreamNonBlocking), "hipStreamCreate");
+        for (hipEvent_t* e : {&ds.fork, &ds.side_done, &ds.accumulated})
+            if (!*e) hip_check(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate");
     }
-    bool brute = (o.flags & PT_FLAG_BRUTE_FORCE) != 0;
-    std::vector<hipEvent_t> seg_events;
-    bool profile = stats && (o.flags & PT_FLAG_PROFILE) != 0;
+
+    std::vector<hipEvent_t> events; // [0], [1]: around the render (stats); then pairs around search launches (profile)
     struct EventCleanup {
         std::vector<hipEvent_t>& v;
         ~EventCleanup() {
             for (hipEvent_t e : v) (void)hipEventDestroy(e);
         }
-    } cleanup{seg_events};
-    uint64_t paths = 0;
+    } cleanup{events};
+    std::vector<hipEvent_t> seg_events;
+    EventCleanup seg_cleanup{seg_events};
+    // A failure while enqueueing leaves launches behind that no event covers: wait for the device
+    // before the error travels on, so that the next call finds the workspaces idle.
+    struct DrainOnFailure {
+        bool armed = true;
+        ~DrainOnFailure() {
+            if (armed) (void)hipDeviceSynchronize();
+        }
+    } drain;
+    // whatever used the workspaces last (another scene, another stream) comes first
+    stream_acquire(ds, 0, stream);
+    if (two) {
+        hip_check(hipEventRecord(ds.fork, stream), "hipEventRecord");
+        hip_check(hipStreamWaitEvent(ds.side, ds.fork, 0), "hipStreamWaitEvent");
+        stream_acquire(ds, 1, ds.side);
+    }
+    if (stats) {
+        hipEvent_t e = nullptr;
+        hip_check(hipEventCreate(&e), "hipEventCreate");
+        events.push_back(e);
+        hip_check(hipEventCreate(&e), "hipEventCreate");
+        events.push_back(e);
+        hip_check(hipMemsetAsync(ds.ws[0].ray_total, 0, 2 * sizeof(uint64_t), stream), "hipMemsetAsync");
+        if (two) hip_check(hipMemsetAsync(ds.ws[1].ray_total, 0, 2 * sizeof(uint64_t), ds.side), "hipMemsetAsync");
+        hip_check(hipEventRecord(events[0], stream), "hipEventRecord");
+    }
+    uint64_t paths = 0, batch_index = 0;
+    bool side_holds_contrib = false; // workspace 1's colours are still to be read by an accumulate on `stream`
     for (uint32_t br = 0; br < total_block_rows; br += band_block_rows) {
         ptk::BatchGeometry g;
         g.x0 = x0;
@@ -659,26 +811,45 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
         g.nbx = nbx;
         g.nby = (g.h + 7) / 8;
         g.npp = g.nbx * g.nby * 64;
-        for (uint64_t s = 0; s < task->iterations; s += samples_per_batch) {
-            uint32_t cnt = (uint32_t)std::min<uint64_t>(samples_per_batch, task->iterations - s);
+        for (uint64_t s = 0; s < task->iterations; s += samples_per_batch, batch_index++) {
+            const uint32_t cnt = (uint32_t)std::min<uint64_t>(samples_per_batch, task->iterations - s);
+            const int k = two ? (int)(batch_index & 1u) : 0;
+            hipStream_t st = k ? ds.side : stream;
+            // workspace 1 is free again once the colours of its previous batch have been added to the image
+            if (k == 1 && side_holds_contrib) hip_check(hipStreamWaitEvent(ds.side, ds.accumulated, 0), "hipStreamWaitEvent");
             hip_check(ptk::render_batch(scene->d, cam, g, o.seed, o.sample_offset + s, cnt, (uint32_t)task->trace_depth,
-                                        brute, scene->targets, scene->ws, d_accum, stream,
+                                        brute, scene->targets, scene->run_slots, ds.ws[k], st,
                                         profile ? &seg_events : nullptr),
                       "render_batch");
+            if (k == 1) {
+                hip_check(hipEventRecord(ds.side_done, ds.side), "hipEventRecord");
+                hip_check(hipStreamWaitEvent(stream, ds.side_done, 0), "hipStreamWaitEvent");
+            }
+            // the per-pixel sums stay in sample order: every batch is added on the caller's stream, in batch order
+            hip_check(ptk::accumulate_batch(g, cam.width, cnt, ds.ws[k], d_accum, stream), "accumulate_batch");
+            if (k == 1) {
+                hip_check(hipEventRecord(ds.accumulated, stream), "hipEventRecord");
+                side_holds_contrib = true;
+            }
             paths += (uint64_t)cnt * g.w * g.h;
         }
     }
+    stream_release(ds, 0, stream);
+    if (two) stream_release(ds, 1, stream); // `stream` has waited for everything queued on the side stream
+    drain.armed = false;
     if (stats) {
-        hip_check(hipEventRecord(ev1, stream), "hipEventRecord");
-        hip_check(hipEventSynchronize(ev1), "hipEventSynchronize");
+        hip_check(hipEventRecord(events[1], stream), "hipEventRecord");
+        hip_check(hipEventSynchronize(events[1]), "hipEventSynchronize");
         float ms = 0.0f;
-        hip_check(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime");
+        hip_check(hipEventElapsedTime(&ms, events[0], events[1]), "hipEventElapsedTime");
         uint64_t totals[2] = {0, 0};
-        hip_check(hipMemcpy(totals, scene->ws.ray_total, sizeof(totals), hipMemcpyDeviceToHost), "hipMemcpy D2H");
-        uint64_t rays = totals[0];
-        (void)hipEventDestroy(ev0);
-        (void)hipEventDestroy(ev1);
-        stats->rays = task->trace_depth ? rays : 0;
+        for (int k = 0; k < (two ? 2 : 1); k++) {
+            uint64_t part[2] = {0, 0};
+            hip_check(hipMemcpy(part, ds.ws[k].ray_total, sizeof(part), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+            totals[0] += part[0];
+            totals[1] += part[1];
+        }
+        stats->rays = task->trace_depth ? totals[0] : 0;
         stats->paths = paths;
         stats->render_ms = ms;
         stats->bvh_bytes = scene->bvh_bytes;
@@ -721,8 +892,10 @@ PtStatus pt_scene_create(const PtSceneDesc* desc, int device, PtScene** out_scen
         hip_check(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
         if (device < 0 || device >= ndev) throw Error(PT_ERR_DEVICE, "no such HIP device");
         DeviceGuard guard(device);
+        auto t_create = std::chrono::steady_clock::now();
         auto s = std::make_unique<PtScene>();
         s->device = device;
+        memset(&s->info, 0, sizeof(s->info));
 
         std::vector<ptk::DNode> nodes;
         layout_nodes(*desc, nodes);
@@ -845,9 +1018,13 @@ PtStatus pt_scene_create(const PtSceneDesc* desc, int device, PtScene** out_scen
             s->d.run.child_count = (uint32_t)run.children.size();
             s->d.run.first_node = run.first_node;
             s->d.run.end_node = run.end_node;
-            s->ws.run_slots = std::min<uint32_t>((uint32_t)run.children.size(), kRunSlotsPerRay);
+            s->run_slots = std::min<uint32_t>((uint32_t)run.children.size(), kRunSlotsPerRay);
         }
         hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        s->info.mesh_count = desc->mesh_count;
+        s->info.bvh_bytes = s->bvh_bytes;
+        s->info.instance_run_children = s->d.run.child_count;
+        s->info.setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count();
         *out_scene = s.release();
     });
 }
@@ -859,6 +1036,29 @@ void pt_scene_destroy(PtScene* scene) {
         delete scene;
     } catch (...) {
     }
+}
+
+PtStatus pt_scene_info(const PtScene* scene, PtSceneInfo* out_info) {
+    return guarded([&] {
+        if (!scene || !out_info) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        *out_info = scene->info;
+    });
+}
+
+PtStatus pt_device_release_workspace(int device) {
+    return guarded([&] {
+        int ndev = 0;
+        hip_check(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
+        if (device < 0 || device >= ndev) throw Error(PT_ERR_DEVICE, "no such HIP device");
+        DeviceGuard guard(device);
+        DeviceState& ds = device_state(device);
+        std::lock_guard<std::mutex> lock(ds.mu);
+        for (int k = 0; k < 2; k++) {
+            wait_idle(ds, k);
+            free_workspace(ds.ws[k]);
+            free_trace_state(ds.ws[k]);
+        }
+    });
 }
 
 PtStatus pt_render_accumulate_device(PtScene* scene, const PtRenderTask* task, const PtRenderOpts* opts, float* d_accum,
@@ -988,13 +1188,39 @@ PtStatus pt_trace_closest(PtScene* scene, const PtRay* rays, size_t n, uint32_t 
     return guarded([&] {
         if (!scene || (n && (!rays || !out_hits))) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
         if (n == 0) return;
+        const bool brute = (flags & PT_FLAG_BRUTE_FORCE) != 0;
+        const bool wavefront = (flags & (PT_FLAG_WAVEFRONT | PT_FLAG_WAVEFRONT_SPLIT)) != 0;
+        if (wavefront) {
+            if (brute) throw Error(PT_ERR_INVALID_ARGUMENT, "the wavefront route has no linear-scan mode");
+            if (n > 0x7FFFFFFFull) throw Error(PT_ERR_UNSUPPORTED, "more than 2^31 rays in one wavefront trace");
+            // the queues of a render carry no ray.max: every ray of a render has f32::MAX (work_group.rs:43, camera.rs:82)
+            for (size_t i = 0; i < n; i++)
+                if (!(rays[i].max == 3.4028234663852886e38f))
+                    throw Error(PT_ERR_UNSUPPORTED, "the wavefront route takes rays with max = f32::MAX only");
+        }
         DeviceGuard guard(scene->device);
+        DeviceState& ds = device_state(scene->device);
+        std::lock_guard<std::mutex> lock(ds.mu);
         DevBuf d_rays(n * sizeof(PtRay)), d_hits(n * sizeof(PtHit));
         hip_check(hipMemcpy(d_rays.p, rays, n * sizeof(PtRay), hipMemcpyHostToDevice), "hipMemcpy H2D");
-        scene->ensure_trace_state();
-        hip_check(ptk::trace_closest(scene->d, static_cast<const PtRay*>(d_rays.p), n, (flags & PT_FLAG_BRUTE_FORCE) != 0,
-                                     static_cast<PtHit*>(d_hits.p), scene->ws, nullptr),
-                  "trace_closest");
+        ensure_trace_state(ds, 0);
+        if (wavefront) {
+            const uint32_t waves = ds.ws[0].persistent_blocks * (ptk::kTraceBlock / 64);
+            const uint64_t records = (uint64_t)ptk::injected_region_capacity(n, waves) * waves;
+            if (!ensure_workspace(ds, 0, records, n, scene->result_arrays(), scene->run_slots))
+                throw Error(PT_ERR_DEVICE, "out of device memory for the trace's queues");
+        }
+        stream_acquire(ds, 0, nullptr);
+        if (wavefront)
+            hip_check(ptk::trace_closest_wavefront(scene->d, scene->targets, scene->run_slots, static_cast<const PtRay*>(d_rays.p),
+                                                   n, static_cast<PtHit*>(d_hits.p), (flags & PT_FLAG_WAVEFRONT_SPLIT) != 0,
+                                                   ds.ws[0], nullptr),
+                      "trace_closest_wavefront");
+        else
+            hip_check(ptk::trace_closest(scene->d, static_cast<const PtRay*>(d_rays.p), n, brute, static_cast<PtHit*>(d_hits.p),
+                                         ds.ws[0], nullptr),
+                      "trace_closest");
+        stream_release(ds, 0, nullptr);
         hip_check(hipMemcpy(out_hits, d_hits.p, n * sizeof(PtHit), hipMemcpyDeviceToHost), "hipMemcpy D2H");
     });
 }
@@ -1050,6 +1276,36 @@ PtStatus pt_host_scene_load(const char* root_dir, const char* scene_path, PtHost
         auto hs = std::make_unique<PtHostScene>();
         hs->scene = pt::load_scene(store, scene_path);
         *out = hs.release();
+    });
+}
+
+PtStatus pt_host_scene_cache_trees(PtHostScene* scene, const char* root_dir, uint32_t* out_written) {
+    return guarded([&] {
+        if (!scene || !scene->scene || !root_dir) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        pt::HostScene& hs = *scene->scene;
+        pt::FileStore store(root_dir);
+        uint32_t written = 0;
+        std::vector<uint8_t> settled(hs.trees.size(), 0); // this call has dealt with the file (one mesh per file)
+        for (size_t i = 0; i + 1 < hs.nodes.size(); i++) {
+            const PtNodeDesc& nd = hs.nodes[i];
+            if (nd.type != PT_NODE_KD_TREE || hs.nodes[i + 1].type != PT_NODE_MESH || nd.tree_id == PT_NO_INDEX) continue;
+            const uint32_t t = nd.tree_id, m = hs.nodes[i + 1].mesh_id;
+            if (t >= hs.trees.size() || m >= hs.meshes.size() || settled[t]) continue;
+            settled[t] = 1;
+            const pt::HostMesh& mesh = hs.meshes[m];
+            if (mesh.triangle_count == 0) continue;
+            pt::BuiltBvh bvh;
+            if (!hs.trees[t].empty() &&
+                pt::deserialize_tree(hs.trees[t].data(), hs.trees[t].size(), mesh.positions.data(), mesh.triangle_count, &bvh))
+                continue; // a hit: nothing to write
+            bvh = pt::build_bvh(mesh.positions.data(), mesh.triangle_count, 4);
+            std::vector<uint8_t> blob = pt::serialize_tree(bvh, mesh.positions.data(), mesh.triangle_count);
+            store.write_file(hs.tree_paths[t], blob);
+            hs.trees[t] = std::move(blob);
+            written++;
+        }
+        hs.finalize(); // the description's blob table points at the new contents
+        if (out_written) *out_written = written;
     });
 }
 

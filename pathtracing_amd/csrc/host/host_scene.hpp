@@ -38,6 +38,8 @@ public:
     explicit FileStore(std::string root_dir) : root_(std::move(root_dir)) {}
     std::vector<uint8_t> fetch_file(const std::string& path) const;
     bool exists(const std::string& path) const;
+    // Replaces (or creates) the file: written beside it under a temporary name, then renamed over it.
+    void write_file(const std::string& path, const std::vector<uint8_t>& data) const;
 
 private:
     std::string root_;

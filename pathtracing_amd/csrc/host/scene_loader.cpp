@@ -2,6 +2,8 @@
 // (worker/src/api/render_task.rs:5-49, worker/src/camera.rs:8-48), reading the
 // same files from a local directory instead of MongoDB GridFS
 // (worker/src/file_store.rs:27-35).
+#include <unistd.h>
+
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -46,6 +48,20 @@ std::vector<uint8_t> FileStore::fetch_file(const std::string& path) const {
     fclose(f);
     if (bad) throw Error(PT_ERR_IO, "read error on '" + full + "'");
     return out;
+}
+
+void FileStore::write_file(const std::string& path, const std::vector<uint8_t>& data) const {
+    std::string full = join_path(root_, path);
+    std::string tmp = full + ".tmp" + std::to_string((long long)getpid());
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) throw Error(PT_ERR_IO, "cannot create '" + tmp + "'");
+    size_t n = data.empty() ? 0 : fwrite(data.data(), 1, data.size(), f);
+    bool bad = n != data.size() || fflush(f) != 0;
+    bad = (fclose(f) != 0) || bad;
+    if (bad || rename(tmp.c_str(), full.c_str()) != 0) {
+        remove(tmp.c_str());
+        throw Error(PT_ERR_IO, "cannot write '" + full + "'");
+    }
 }
 
 // --------------------------------------------------------------- JSON helpers

@@ -926,10 +926,11 @@ __device__ __forceinline__ int walk(const DScene& sc, WalkState& w, Hit& cur, bo
 // walk(): node_collection.rs:43-55 around sphere.rs / plane.rs / transform.rs + hierarchy/mesh.rs.
 // `res[m][index]` = the closest triangle of the scene's m-th mesh node for this ray where bit m of
 // `listed` is set (m below `deferred`; further mesh nodes are searched here); `live_meshes`, `run` as in walk().
+// `all_uv` as in walk().
 template <bool kRun>
 __device__ __forceinline__ void walk_flat(const DScene& sc, const Ray& world, float4* const* res, size_t index,
                                           uint32_t deferred, uint32_t listed, uint32_t live_meshes, const RunLookup* run,
-                                          TravStack& st, Hit* out) {
+                                          TravStack& st, Hit* out, bool all_uv = false) {
     ConstNodePtr nodes = const_nodes(sc);
     Hit best;
     best.hit = 0u;
@@ -960,7 +961,7 @@ __device__ __forceinline__ void walk_flat(const DScene& sc, const Ray& world, fl
                 nd.radius_sqr = nodes[i].radius_sqr;
                 nd.material_id = nodes[i].material_id;
                 typedef const __attribute__((address_space(4))) DMaterial* ConstMaterialPtr;
-                bool want_uv = ((ConstMaterialPtr)(unsigned long long)sc.materials)[nd.material_id].color_is_texture != 0u;
+                bool want_uv = all_uv || ((ConstMaterialPtr)(unsigned long long)sc.materials)[nd.material_id].color_is_texture != 0u;
                 sphere_trace(nd, i, world, &cur, want_uv);
             } else if (type == 4u) {
                 DNode nd;

@@ -32,9 +32,8 @@ struct Workspace {
     float4* results[16] = {};
     // per queue, per ray: which of the searched mesh nodes the ray has a job (and so a result) for
     uint32_t* listed[2] = {nullptr, nullptr};
-    // instance run: job slots per ray set aside for its children, per ray the head of its chain of
-    // jobs (indexed like a queue), per job its result (indexed like `jobs`)
-    uint32_t run_slots = 0;
+    // instance run: per ray the head of its chain of jobs (indexed like a queue), per job its
+    // result (indexed like `jobs`)
     uint32_t* run_head = nullptr;
     float4* run_res = nullptr;
     // the segment's hit per ray, indexed like a queue: (point, material | inside << 31) (normal, uv.x), uv.y
@@ -43,6 +42,7 @@ struct Workspace {
     float* contrib = nullptr;    // 3 floats per path of the batch: its final colour
     uint64_t capacity_paths = 0; // records each queue array holds
     uint64_t contrib_paths = 0;  // paths the contribution buffer holds
+    uint32_t result_arrays = 0;  // how many of results[] are allocated
     uint64_t* ray_total = nullptr; // device-side running sums: [0] traced rays, [1] BVH searches
     // Trace kernels run a persistent grid of `persistent_blocks` blocks; `spill`
     // holds one column of spill_dwords() dwords per thread of that grid.
@@ -65,16 +65,33 @@ struct BatchGeometry {
     uint32_t npp;          // path slots per sample = nbx * nby * 64
 };
 
-// Runs samples [sample_first, sample_first + sample_count) of every pixel of the
-// rectangle and adds their colours, in sample order, into d_accum (camera-space
-// layout, (x + y*W)*3).
-// `targets`: the scene graph's mesh nodes in array order.
+// Traces samples [sample_first, sample_first + sample_count) of every pixel of the
+// rectangle: every path's final colour ends up in ws.contrib (accumulate_batch adds
+// them to the image).
+// `targets`: the scene graph's mesh nodes in array order.  `run_slots`: job slots per
+// ray set aside for the children of the scene's instance run (0: the scene has none).
 // `search_events`: when non-null, a pair of events (start, stop) is created and
 // recorded around every search_kernel launch and appended to the vector.
 hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeometry& geo, uint64_t seed,
                         uint64_t sample_first, uint32_t sample_count, uint32_t trace_depth, bool brute,
-                        const std::vector<MeshTarget>& targets, Workspace& ws, float* d_accum, hipStream_t stream,
+                        const std::vector<MeshTarget>& targets, uint32_t run_slots, Workspace& ws, hipStream_t stream,
                         std::vector<hipEvent_t>* search_events);
+
+// Adds a traced batch's colours, per pixel in sample order, into d_accum
+// (camera-space layout, (x + y*W)*3).
+hipError_t accumulate_batch(const BatchGeometry& geo, uint32_t width, uint32_t sample_count, const Workspace& ws,
+                            float* d_accum, hipStream_t stream);
+
+// Records per wave region that `n` rays handed in through trace_closest_wavefront need.
+uint32_t injected_region_capacity(size_t n, uint32_t waves);
+
+// scene.hierarchy.trace_ray for n rays (ray.max = f32::MAX, as every ray of a render
+// has) through the kernels a render uses: the rays go into the wave regions of a
+// queue, their BVH searches are listed, search_kernel runs them, the walk reads the
+// results.  `split`: walk_kernel even where a render would use walk_bounce_kernel.
+hipError_t trace_closest_wavefront(const DScene& scene, const std::vector<MeshTarget>& targets, uint32_t run_slots,
+                                   const PtRay* d_rays, size_t n, PtHit* d_hits, bool split, Workspace& ws,
+                                   hipStream_t stream);
 
 hipError_t resolve_image(const float* d_accum, uint32_t width, uint32_t height, float scale, float* d_out,
                          hipStream_t stream);

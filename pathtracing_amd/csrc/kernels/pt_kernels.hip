@@ -187,6 +187,21 @@ __device__ __forceinline__ uint32_t list_searches(const DScene& scene, const Sea
     return listed;
 }
 
+// The hit record of the closest-hit contract (PtHit) from the tracer's own.
+__device__ __forceinline__ PtHit to_pt_hit(const Hit& h) {
+    PtHit o;
+    o.hit = h.hit;
+    o.hit_inside = h.hit_inside;
+    o.node_index = h.hit ? h.node_index : 0xFFFFFFFFu;
+    o.tri_index = h.hit ? h.tri_index : 0xFFFFFFFFu;
+    o.material_id = h.material_id;
+    o.t = h.t;
+    o.point = {h.point.x, h.point.y, h.point.z};
+    o.normal = {h.normal.x, h.normal.y, h.normal.z};
+    o.uv = {h.uv.x, h.uv.y};
+    return o;
+}
+
 // -------------------------------------------------------------- camera kernel
 // Camera::get_ray (camera.rs:51-83) for every path of the batch: path slot ->
 // (sample, pixel), the first draws of the path's random stream, the ray into the
@@ -269,6 +284,61 @@ camera_kernel(RenderParams p, SegmentBuffers b, SearchList sl, uint32_t cap, uin
     if (lane == 0u && listed) atomicAdd(sl.search_total, listed);
 }
 
+// -------------------------------------------------------------- inject kernel
+// camera_kernel's place for rays that come from the caller (pt_trace_closest on the
+// wavefront route): chunk c of 64 rays goes to region c mod regions, the path id of a
+// ray is its index, and the rays' searches are listed exactly as for camera rays.
+template <bool kRun>
+__global__ void __launch_bounds__(kBlock)
+inject_kernel(DScene scene, const PtRay* __restrict__ rays, uint32_t n, SegmentBuffers b, SearchList sl, uint32_t cap,
+              uint32_t regions) {
+    const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+    const uint32_t waves = (gridDim.x * kBlock) >> 6;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const uint32_t chunks = (n + 63u) / 64u;
+    unsigned long long listed = 0;
+    for (uint32_t r = wave; r < regions; r += waves) {
+        const size_t base = (size_t)r * cap;
+        uint32_t out_pos = 0u, job_pos = 0u, run_used = 0u;
+        for (uint32_t c = r; c < chunks; c += regions) {
+            const uint32_t i = c * 64u + lane;
+            const bool have = i < n;
+            Ray ray;
+            ray.source = mk3(0, 0, 0);
+            ray.direction = mk3(0, 0, 0);
+            ray.min = 0.0f;
+            ray.max = kF32Max;
+            if (have) {
+                PtRay in = rays[i];
+                ray.source = mk3(in.source.x, in.source.y, in.source.z);
+                ray.direction = mk3(in.direction.x, in.direction.y, in.direction.z);
+                ray.min = in.min;
+            }
+            unsigned long long mask = __ballot(have);
+            const uint32_t item = out_pos + (uint32_t)__popcll(mask & lane_lt);
+            if (have) {
+                size_t o = base + item;
+                b.ray_a[o] = make_float4(ray.source.x, ray.source.y, ray.source.z, ray.min);
+                b.ray_b[o] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, __uint_as_float(i));
+                b.ray_c[o] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(0u));
+            }
+            if (sl.count | sl.run) {
+                const uint32_t mine = list_searches<kRun>(scene, sl, have, ray, r, cap, item, job_pos, run_used, lane_lt);
+                if (have && sl.count) b.listed[base + item] = mine;
+            }
+            out_pos += (uint32_t)__popcll(mask);
+        }
+        if (lane == 0u) {
+            b.ray_counts[r] = out_pos;
+            if (sl.count | sl.run) sl.job_counts[r] = job_pos;
+        }
+        listed += job_pos;
+    }
+    if (lane == 0u && listed) atomicAdd(sl.search_total, listed);
+}
+
 // ---------------------------------------------------------------- walk kernel
 // hierarchy.trace_ray of a path segment (work_group.rs:30) with the BVH searches
 // already done: the scene-graph walk, with the closest triangle of every mesh node
@@ -280,10 +350,12 @@ camera_kernel(RenderParams p, SegmentBuffers b, SearchList sl, uint32_t cap, uin
 // otherwise the general resumable walk.
 // Waves per SIMD the kernel is compiled for: four without the instance-run code (128 registers:
 // the loop over a flat root's children and the general walk both fit), three with it.
-template <bool kRun, bool kFlat>
+// kFull: the whole hit record of every ray goes to full_hits[path id] as well (the closest-hit
+// contract on the wavefront route; a render needs only what the bounce reads).
+template <bool kRun, bool kFlat, bool kFull = false>
 __global__ void __launch_bounds__(kBlock, kRun ? 3 : 4)
 walk_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions, unsigned long long* ray_total,
-            uint32_t* spill, uint32_t spill_threads) {
+            uint32_t* spill, uint32_t spill_threads, PtHit* full_hits = nullptr) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -337,7 +409,8 @@ walk_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions, un
                 look.run_res = b.run_res + (size_t)r * b.job_cap;
             }
             if (kFlat) {
-                walk_flat<kRun>(p.scene, ray, b.res, base + item, (uint32_t)kMaxDeferred, listed, live, have_run ? &look : nullptr, st, &cur);
+                walk_flat<kRun>(p.scene, ray, b.res, base + item, (uint32_t)kMaxDeferred, listed, live, have_run ? &look : nullptr, st, &cur, kFull);
+                if (kFull) full_hits[__float_as_uint(rb.w)] = to_pt_hit(cur);
                 uint32_t tag = cur.hit ? (cur.material_id | (cur.hit_inside << 31)) : 0xFFFFFFFFu;
                 b.hit_a[base + item] = make_float4(cur.point.x, cur.point.y, cur.point.z, __uint_as_float(tag));
                 b.hit_b[base + item] = make_float4(cur.normal.x, cur.normal.y, cur.normal.z, cur.uv.x);
@@ -348,7 +421,7 @@ walk_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions, un
             TravState ts;
             walk_begin(w, ray);
             bool resume = false;
-            while (walk<kRun>(p.scene, w, cur, resume, brute, st, false, live, have_run ? &look : nullptr) == kWalkMesh) {
+            while (walk<kRun>(p.scene, w, cur, resume, brute, st, kFull, live, have_run ? &look : nullptr) == kWalkMesh) {
                 const uint32_t m = const_nodes(p.scene)[__builtin_amdgcn_readfirstlane(w.i)].mesh_ordinal;
                 if (m < (uint32_t)kMaxDeferred) {
                     float4 res = make_float4(f32_inf(), __uint_as_float(0u), __uint_as_float(0u), __uint_as_float(0xFFFFFFFFu));
@@ -363,6 +436,7 @@ walk_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions, un
                 walk_mesh_result(p.scene, w, ts, &cur);
                 resume = true;
             }
+            if (kFull) full_hits[__float_as_uint(rb.w)] = to_pt_hit(cur);
             uint32_t tag = cur.hit ? (cur.material_id | (cur.hit_inside << 31)) : 0xFFFFFFFFu;
             b.hit_a[base + item] = make_float4(cur.point.x, cur.point.y, cur.point.z, __uint_as_float(tag));
             b.hit_b[base + item] = make_float4(cur.normal.x, cur.normal.y, cur.normal.z, cur.uv.x);
@@ -510,9 +584,12 @@ bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList sl, u
 // bounce is bound by its memory traffic).  168 registers, three waves per SIMD; fetching the next
 // chunk's records ahead, as bounce_kernel does, costs more in spills than it hides here.  Scenes with an instance run keep the two kernels: the
 // walk reads the segment's job list while the bounce overwrites it with the next segment's.
+// kFull: as in walk_kernel.
+template <bool kFull = false>
 __global__ void __launch_bounds__(kBlock, 3)
 walk_bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList sl, uint32_t cap, uint32_t regions,
-                   float* contrib, unsigned long long* ray_total, uint32_t* spill, uint32_t spill_threads) {
+                   float* contrib, unsigned long long* ray_total, uint32_t* spill, uint32_t spill_threads,
+                   PtHit* full_hits = nullptr) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -563,9 +640,10 @@ walk_bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList 
                 ray.direction = mk3(rb.x, rb.y, rb.z);
                 ray.max = kF32Max;
                 Hit cur;
-                walk_flat<false>(p.scene, ray, b.res, base + item, (uint32_t)kMaxDeferred, listed, live, nullptr, st, &cur);
+                walk_flat<false>(p.scene, ray, b.res, base + item, (uint32_t)kMaxDeferred, listed, live, nullptr, st, &cur, kFull);
                 // ---- the rest of the segment (work_group.rs:31-47)
                 path = __float_as_uint(rb.w);
+                if (kFull) full_hits[path] = to_pt_hit(cur);
                 rng_counter = __float_as_uint(rc.w);
                 V3 color = mk3(0, 0, 0);
                 bool finished = true;
@@ -864,17 +942,7 @@ __global__ void __launch_bounds__(kBlock, 4) trace_closest_kernel(DScene scene, 
         ray.max = r.max;
         Hit h;
         scene_trace(scene, ray, brute != 0u, st, &h);
-        PtHit o;
-        o.hit = h.hit;
-        o.hit_inside = h.hit_inside;
-        o.node_index = h.hit ? h.node_index : 0xFFFFFFFFu;
-        o.tri_index = h.hit ? h.tri_index : 0xFFFFFFFFu;
-        o.material_id = h.material_id;
-        o.t = h.t;
-        o.point = {h.point.x, h.point.y, h.point.z};
-        o.normal = {h.normal.x, h.normal.y, h.normal.z};
-        o.uv = {h.uv.x, h.uv.y};
-        hits[gid] = o;
+        hits[gid] = to_pt_hit(h);
     }
 }
 
@@ -941,9 +1009,117 @@ static_assert(kTraceBlock == (uint32_t)kBlock, "block size mismatch");
 
 static inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
+uint32_t injected_region_capacity(size_t n, uint32_t waves) {
+    uint64_t chunks = ((uint64_t)n + 63) / 64;
+    uint64_t per_wave = waves ? (chunks + waves - 1) / waves : chunks;
+    return (uint32_t)(std::max<uint64_t>(per_wave, 1) * 64);
+}
+
+namespace {
+
+// The device pointers of a launch sequence over a workspace whose queues are cut into
+// `regions` regions of `cap` records.
+struct SegmentPlan {
+    uint32_t cap = 0, regions = 0;
+    uint32_t searched = 0;  // mesh nodes searched ahead of the walk
+    uint32_t run_slots = 0; // job slots per ray for the children of the instance run
+    uint32_t spill_threads = 0;
+    SearchList sl;
+    SearchResults sr;
+    unsigned long long* totals = nullptr;
+    const Workspace* ws = nullptr;
+
+    SegmentBuffers buffers(int in) const {
+        const Workspace& w = *ws;
+        int out = in ^ 1;
+        SegmentBuffers b;
+        b.ray_a = w.queue[in][0];
+        b.ray_b = w.queue[in][1];
+        b.ray_c = w.queue[in][2];
+        b.ray_counts = w.wave_counts[in];
+        b.next_a = w.queue[out][0];
+        b.next_b = w.queue[out][1];
+        b.next_c = w.queue[out][2];
+        b.next_counts = w.wave_counts[out];
+        for (int k = 0; k < kMaxDeferred; k++) b.res[k] = w.results[k];
+        b.hit_a = w.hits[0];
+        b.hit_b = w.hits[1];
+        b.hit_c = w.hit_uv_y;
+        b.listed = w.listed[in];
+        b.next_listed = w.listed[out];
+        b.run_head = w.run_head;
+        b.run_job_c = w.jobs[2];
+        b.run_res = w.run_res;
+        b.job_cap = cap * (searched + run_slots);
+        return b;
+    }
+};
+
+// Checks that the workspace holds what the launches will touch (a kernel handed a null or short
+// array would fault the GPU) and fills the plan.
+hipError_t make_plan(const DScene& scene, size_t target_count, uint32_t run_slots_cfg, bool brute, const Workspace& ws,
+                     uint32_t cap, uint64_t paths, SegmentPlan* plan) {
+    if (!ws.spill || !ws.wave_counts[0] || !ws.wave_counts[1] || !ws.job_counts || !ws.ray_total || !ws.hits[0] ||
+        !ws.hits[1] || !ws.hit_uv_y || !ws.contrib || ws.persistent_blocks == 0)
+        return hipErrorInvalidValue;
+    for (int q = 0; q < 2; q++)
+        for (int k = 0; k < 3; k++)
+            if (!ws.queue[q][k]) return hipErrorInvalidValue;
+    SegmentPlan& pl = *plan;
+    pl.ws = &ws;
+    pl.regions = ws.persistent_blocks * (kBlock / 64);
+    pl.cap = cap;
+    if ((uint64_t)cap * pl.regions > ws.capacity_paths || paths > ws.contrib_paths) return hipErrorInvalidValue;
+    // mesh nodes searched ahead of the walk; the linear-scan mode searches nothing ahead
+    pl.searched = brute ? 0u : std::min<uint32_t>((uint32_t)target_count, (uint32_t)kMaxDeferred);
+    if (pl.searched > ws.result_arrays) return hipErrorInvalidValue;
+    for (uint32_t m = 0; m < pl.searched; m++)
+        if (!ws.results[m]) return hipErrorInvalidValue;
+    // job slots per ray for the children of the instance run (more candidates than that are searched while walking)
+    pl.run_slots = (!brute && scene.run.child_count != 0u) ? run_slots_cfg : 0u;
+    if (pl.run_slots && (!ws.run_head || !ws.run_res)) return hipErrorInvalidValue;
+    if (pl.searched && (!ws.listed[0] || !ws.listed[1])) return hipErrorInvalidValue;
+    pl.spill_threads = ws.persistent_blocks * kBlock;
+    pl.totals = reinterpret_cast<unsigned long long*>(ws.ray_total);
+    memset(&pl.sl, 0, sizeof(pl.sl));
+    for (int k = 0; k < kMaxDeferred; k++) pl.sr.res[k] = ws.results[k];
+    pl.sr.run_res = ws.run_res;
+    if (pl.searched || pl.run_slots) {
+        if (!ws.jobs[0] || !ws.jobs[1] || !ws.jobs[2] ||
+            (uint64_t)cap * (pl.searched + pl.run_slots) * pl.regions > ws.job_records)
+            return hipErrorInvalidValue;
+        // the kernels that queue rays list the searches of those rays (every mesh node searched ahead of the walk)
+        pl.sl.job_a = ws.jobs[0];
+        pl.sl.job_b = ws.jobs[1];
+        pl.sl.job_c = ws.jobs[2];
+        pl.sl.job_counts = ws.job_counts;
+        pl.sl.search_total = pl.totals + 1;
+        pl.sl.count = pl.searched;
+        pl.sl.run = pl.run_slots ? 1u : 0u;
+        pl.sl.run_cap = cap * pl.run_slots;
+        pl.sl.job_cap = cap * (pl.searched + pl.run_slots);
+        pl.sl.run_head = ws.run_head;
+    }
+    return hipSuccess;
+}
+
+void launch_search(const DScene& scene, const SegmentPlan& pl, hipStream_t stream) {
+    const Workspace& ws = *pl.ws;
+    if (scene.mesh_count == 1u)
+        search_kernel<true><<<ws.persistent_blocks, kBlock, 0, stream>>>(scene.meshes, scene.mesh0, ws.jobs[0], ws.jobs[1],
+                                                                        ws.jobs[2], ws.job_counts, pl.sr, pl.cap, pl.sl.job_cap,
+                                                                        pl.regions, ws.spill, pl.spill_threads);
+    else
+        search_kernel<false><<<ws.persistent_blocks, kBlock, 0, stream>>>(scene.meshes, scene.mesh0, ws.jobs[0], ws.jobs[1],
+                                                                         ws.jobs[2], ws.job_counts, pl.sr, pl.cap, pl.sl.job_cap,
+                                                                         pl.regions, ws.spill, pl.spill_threads);
+}
+
+} // namespace
+
 hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeometry& geo, uint64_t seed,
                         uint64_t sample_first, uint32_t sample_count, uint32_t trace_depth, bool brute,
-                        const std::vector<MeshTarget>& targets, Workspace& ws, float* d_accum, hipStream_t stream,
+                        const std::vector<MeshTarget>& targets, uint32_t run_slots_cfg, Workspace& ws, hipStream_t stream,
                         std::vector<hipEvent_t>* search_events) {
     RenderParams p;
     p.scene = scene;
@@ -955,73 +1131,27 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
     p.trace_depth = trace_depth;
     p.brute = brute ? 1u : 0u;
     uint64_t total = (uint64_t)sample_count * geo.npp;
-    if (total == 0 || trace_depth == 0) return hipSuccess;
-    if (!ws.spill || !ws.hits[0] || !ws.hits[1] || !ws.hit_uv_y || ws.persistent_blocks == 0 || total > 0xFFFFFFFFull)
-        return hipErrorInvalidValue;
-    const uint32_t regions = ws.persistent_blocks * (kBlock / 64);
-    const uint32_t cap = queue_region_capacity(geo.nbx, geo.nby, sample_count, regions);
-    if ((uint64_t)cap * regions > ws.capacity_paths || total > ws.contrib_paths) return hipErrorInvalidValue;
-    // mesh nodes searched ahead of the walk; the linear-scan mode searches nothing ahead
-    const uint32_t searched = brute ? 0u : std::min<uint32_t>((uint32_t)targets.size(), (uint32_t)kMaxDeferred);
-    for (uint32_t m = 0; m < searched; m++)
-        if (!ws.results[m]) return hipErrorInvalidValue;
-    // job slots per ray for the children of the instance run (more candidates than that are searched while walking)
-    const uint32_t run_slots = (!brute && scene.run.child_count != 0u) ? ws.run_slots : 0u;
-    if (run_slots && (!ws.run_head || !ws.run_res)) return hipErrorInvalidValue;
-    if (searched && (!ws.listed[0] || !ws.listed[1])) return hipErrorInvalidValue;
-    const uint32_t spill_threads = ws.persistent_blocks * kBlock;
-    unsigned long long* rt = reinterpret_cast<unsigned long long*>(ws.ray_total);
-    hipError_t e;
-    auto buffers = [&](int in) {
-        int out = in ^ 1;
-        SegmentBuffers b;
-        b.ray_a = ws.queue[in][0];
-        b.ray_b = ws.queue[in][1];
-        b.ray_c = ws.queue[in][2];
-        b.ray_counts = ws.wave_counts[in];
-        b.next_a = ws.queue[out][0];
-        b.next_b = ws.queue[out][1];
-        b.next_c = ws.queue[out][2];
-        b.next_counts = ws.wave_counts[out];
-        for (int k = 0; k < kMaxDeferred; k++) b.res[k] = ws.results[k];
-        b.hit_a = ws.hits[0];
-        b.hit_b = ws.hits[1];
-        b.hit_c = ws.hit_uv_y;
-        b.listed = ws.listed[in];
-        b.next_listed = ws.listed[out];
-        b.run_head = ws.run_head;
-        b.run_job_c = ws.jobs[2];
-        b.run_res = ws.run_res;
-        b.job_cap = cap * (searched + run_slots);
-        return b;
-    };
-    // the kernels that queue rays list the searches of those rays (every mesh node searched ahead of the walk)
-    SearchList sl;
-    memset(&sl, 0, sizeof(sl));
-    SearchResults sr;
-    for (int k = 0; k < kMaxDeferred; k++) sr.res[k] = ws.results[k];
-    sr.run_res = ws.run_res;
-    if (searched || run_slots) {
-        if (!ws.jobs[0] || !ws.jobs[1] || !ws.jobs[2] || (uint64_t)cap * (searched + run_slots) * regions > ws.job_records)
-            return hipErrorInvalidValue;
-        sl.job_a = ws.jobs[0];
-        sl.job_b = ws.jobs[1];
-        sl.job_c = ws.jobs[2];
-        sl.job_counts = ws.job_counts;
-        sl.search_total = rt + 1;
-        sl.count = searched;
-        sl.run = run_slots ? 1u : 0u;
-        sl.run_cap = cap * run_slots;
-        sl.job_cap = cap * (searched + run_slots);
-        sl.run_head = ws.run_head;
+    if (total == 0) return hipSuccess;
+    if (total > 0xFFFFFFFFull || ws.persistent_blocks == 0) return hipErrorInvalidValue;
+    if (trace_depth == 0) { // every path is black (work_group.rs:26-51 with max_depth 0)
+        if (!ws.contrib || total > ws.contrib_paths) return hipErrorInvalidValue;
+        return hipMemsetAsync(ws.contrib, 0, total * 3 * sizeof(float), stream);
     }
+    SegmentPlan pl;
+    hipError_t e = make_plan(scene, targets.size(), run_slots_cfg, brute, ws,
+                             queue_region_capacity(geo.nbx, geo.nby, sample_count, ws.persistent_blocks * (kBlock / 64)), total,
+                             &pl);
+    if (e != hipSuccess) return e;
+    const uint32_t cap = pl.cap, regions = pl.regions, spill_threads = pl.spill_threads;
+    const SearchList& sl = pl.sl;
+    unsigned long long* rt = pl.totals;
     // scenes with an instance run get the kernels that know about it; the others carry none of its code
-    const bool with_run = run_slots != 0u;
-    if (with_run) camera_kernel<true><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, buffers(0), sl, cap, regions);
-    else camera_kernel<false><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, buffers(0), sl, cap, regions);
+    const bool with_run = pl.run_slots != 0u;
+    if (with_run) camera_kernel<true><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, pl.buffers(0), sl, cap, regions);
+    else camera_kernel<false><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, pl.buffers(0), sl, cap, regions);
     for (uint32_t d = 0; d < trace_depth; d++) {
-        SegmentBuffers b = buffers((int)(d & 1u));
-        if (searched || run_slots) {
+        SegmentBuffers b = pl.buffers((int)(d & 1u));
+        if (pl.searched || pl.run_slots) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (search_events) {
                 if ((e = hipEventCreate(&e0)) != hipSuccess) return e;
@@ -1030,22 +1160,15 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
                 search_events->push_back(e1);
                 if ((e = hipEventRecord(e0, stream)) != hipSuccess) return e;
             }
-            if (scene.mesh_count == 1u)
-                search_kernel<true><<<ws.persistent_blocks, kBlock, 0, stream>>>(scene.meshes, scene.mesh0, ws.jobs[0], ws.jobs[1],
-                                                                                ws.jobs[2], ws.job_counts, sr, cap, sl.job_cap,
-                                                                                regions, ws.spill, spill_threads);
-            else
-                search_kernel<false><<<ws.persistent_blocks, kBlock, 0, stream>>>(scene.meshes, scene.mesh0, ws.jobs[0], ws.jobs[1],
-                                                                                 ws.jobs[2], ws.job_counts, sr, cap, sl.job_cap,
-                                                                                 regions, ws.spill, spill_threads);
+            launch_search(scene, pl, stream);
             if (search_events && (e = hipEventRecord(e1, stream)) != hipSuccess) return e;
         }
         // one loop over the root's children where the scene has that shape (not in the linear-scan mode,
         // whose searches happen inside the general walk)
         const bool flat = scene.flat_root != 0u && !brute;
         if (flat && !with_run) {
-            walk_bounce_kernel<<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, b, sl, cap, regions, ws.contrib, rt, ws.spill,
-                                                                            spill_threads);
+            walk_bounce_kernel<false><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, b, sl, cap, regions, ws.contrib, rt,
+                                                                                   ws.spill, spill_threads);
             continue;
         }
         if (with_run) {
@@ -1058,7 +1181,58 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
             bounce_kernel<false><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, b, sl, cap, regions, ws.contrib);
         }
     }
-    accumulate_kernel<<<blocks_for(geo.npp), kBlock, 0, stream>>>(geo, cam.width, sample_count, ws.contrib, d_accum);
+    return hipGetLastError();
+}
+
+hipError_t accumulate_batch(const BatchGeometry& geo, uint32_t width, uint32_t sample_count, const Workspace& ws,
+                            float* d_accum, hipStream_t stream) {
+    if (geo.npp == 0 || sample_count == 0) return hipSuccess;
+    if (!ws.contrib || (uint64_t)sample_count * geo.npp > ws.contrib_paths) return hipErrorInvalidValue;
+    accumulate_kernel<<<blocks_for(geo.npp), kBlock, 0, stream>>>(geo, width, sample_count, ws.contrib, d_accum);
+    return hipGetLastError();
+}
+
+hipError_t trace_closest_wavefront(const DScene& scene, const std::vector<MeshTarget>& targets, uint32_t run_slots_cfg,
+                                   const PtRay* d_rays, size_t n, PtHit* d_hits, bool split, Workspace& ws,
+                                   hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    if (n > 0x7FFFFFFFull || ws.persistent_blocks == 0) return hipErrorInvalidValue;
+    SegmentPlan pl;
+    const uint32_t cap = injected_region_capacity(n, ws.persistent_blocks * (kBlock / 64));
+    hipError_t e = make_plan(scene, targets.size(), run_slots_cfg, false, ws, cap, n, &pl);
+    if (e != hipSuccess) return e;
+    // one path segment of a "render" whose path ids are the ray indices; the pixel a path id maps to only
+    // selects the random stream of the bounce that walk_bounce_kernel carries along, whose colour nobody reads
+    RenderParams p;
+    memset(&p, 0, sizeof(p));
+    p.scene = scene;
+    p.cam.width = 1u;
+    p.cam.height = 1u;
+    p.geo.w = 8u;
+    p.geo.h = 0xFFFFFFF8u;
+    p.geo.nbx = 1u;
+    p.geo.nby = 0x1FFFFFFFu;
+    p.geo.npp = 0xFFFFFFFFu;
+    p.sample_count = 1u;
+    p.trace_depth = 1u;
+    const uint32_t regions = pl.regions, spill_threads = pl.spill_threads;
+    const bool with_run = pl.run_slots != 0u;
+    SegmentBuffers b = pl.buffers(0);
+    if (with_run) inject_kernel<true><<<ws.persistent_blocks, kBlock, 0, stream>>>(scene, d_rays, (uint32_t)n, b, pl.sl, cap, regions);
+    else inject_kernel<false><<<ws.persistent_blocks, kBlock, 0, stream>>>(scene, d_rays, (uint32_t)n, b, pl.sl, cap, regions);
+    if (pl.searched || pl.run_slots) launch_search(scene, pl, stream);
+    const bool flat = scene.flat_root != 0u;
+    unsigned long long* rt = pl.totals;
+    if (flat && !with_run && !split) {
+        walk_bounce_kernel<true><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, 0u, b, pl.sl, cap, regions, ws.contrib, rt,
+                                                                              ws.spill, spill_threads, d_hits);
+    } else if (with_run) {
+        if (flat) walk_kernel<true, true, true><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, b, cap, regions, rt, ws.spill, spill_threads, d_hits);
+        else walk_kernel<true, false, true><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, b, cap, regions, rt, ws.spill, spill_threads, d_hits);
+    } else {
+        if (flat) walk_kernel<false, true, true><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, b, cap, regions, rt, ws.spill, spill_threads, d_hits);
+        else walk_kernel<false, false, true><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, b, cap, regions, rt, ws.spill, spill_threads, d_hits);
+    }
     return hipGetLastError();
 }
 

@@ -61,15 +61,27 @@ class HipRenderer:
                                                   C.c_void_p(stream), C.byref(stats) if want_stats else None))
         return stats
 
-    def trace_closest(self, rays: np.ndarray, brute_force: bool = False) -> np.ndarray:
+    def trace_closest(self, rays: np.ndarray, brute_force: bool = False, route: str = "thread") -> np.ndarray:
         """``rays``: float32 ``[n, 8]`` (source, direction, min, max). Returns a
-        structured array with the fields of ``PtHit``."""
+        structured array with the fields of ``PtHit``.  ``route``: ``"thread"`` (one
+        thread per ray, every search in place), ``"wavefront"`` (the kernels a render
+        uses: queue regions, listed searches, the search kernel, the walk) or
+        ``"wavefront_split"`` (the same with the separate walk kernel)."""
         rays = np.ascontiguousarray(rays, dtype=np.float32)
         assert rays.ndim == 2 and rays.shape[1] == 8
         hits = np.zeros(rays.shape[0], dtype=HIT_DTYPE)
-        N.check(N.lib.pt_trace_closest(self._handle, rays.ctypes.data, rays.shape[0],
-                                       N.PT_FLAG_BRUTE_FORCE if brute_force else 0, hits.ctypes.data))
+        flags = {"thread": 0, "wavefront": N.PT_FLAG_WAVEFRONT, "wavefront_split": N.PT_FLAG_WAVEFRONT_SPLIT}[route]
+        if brute_force:
+            flags |= N.PT_FLAG_BRUTE_FORCE
+        N.check(N.lib.pt_trace_closest(self._handle, rays.ctypes.data, rays.shape[0], flags, hits.ctypes.data))
         return hits
+
+    @property
+    def info(self) -> N.PtSceneInfo:
+        """What ``pt_scene_create`` did: .tree files adopted, structures built, times."""
+        out = N.PtSceneInfo()
+        N.check(N.lib.pt_scene_info(self._handle, C.byref(out)))
+        return out
 
     def shade(self, directions: np.ndarray, hits: np.ndarray, stream_ids: np.ndarray, seed: int = 0):
         directions = np.ascontiguousarray(directions, dtype=np.float32)

@@ -34,6 +34,15 @@ class Scene:
         p._owner = self
         return p
 
+    def cache_trees(self, root_dir: str) -> int:
+        """Writes the ``.tree`` file of every ``kd_tree`` node whose file is missing,
+        empty or stale (and takes it into this scene): the next ``Scene.load`` of the
+        same files finds them and ``HipRenderer.init`` skips the build.  Returns the
+        number of files written."""
+        written = C.c_uint32()
+        N.check(N.lib.pt_host_scene_cache_trees(self._handle, root_dir.encode(), C.byref(written)))
+        return int(written.value)
+
     def close(self) -> None:
         if self._handle:
             N.lib.pt_host_scene_destroy(self._handle)

@@ -16,9 +16,10 @@ from .scene import Scene
 class Worker:
     """``scene_root`` replaces the MongoDB URL: scene files are read from that directory."""
 
-    def __init__(self, scene_root: str, device: int = 0):
+    def __init__(self, scene_root: str, device: int = 0, cache_trees: bool = True):
         self.scene_root = scene_root
         self.device = device
+        self.cache_trees = cache_trees  # write missing / stale .tree files back into scene_root
         self.cached_scenes: Dict[str, Scene] = {}
         self._renderers: Dict[str, HipRenderer] = {}
 
@@ -26,6 +27,12 @@ class Worker:
         key = render_task.scene_md5 or render_task.scene
         if key not in self.cached_scenes:
             self.cached_scenes[key] = Scene.load(self.scene_root, render_task.scene)
+            if self.cache_trees:
+                try:
+                    self.cached_scenes[key].cache_trees(self.scene_root)
+                except N.PathTracingError as e:  # a read-only scene directory is no reason to refuse the task
+                    if e.status != 3:  # PT_ERR_IO
+                        raise
         # The reference constructs a renderer per task (lib.rs:44); the device copy of the
         # scene is kept beside the cached host scene so the upload happens once.
         if key not in self._renderers:

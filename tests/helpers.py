@@ -57,6 +57,17 @@ def assert_hits_identical(got: np.ndarray, want: np.ndarray, what: str = "") -> 
         assert bad.size == 0, f"{what}: {name} differs in bits for {bad.size} hits, first {bad[:8]}"
 
 
+ROUTES = ("thread", "wavefront", "wavefront_split")
+
+
+def assert_all_routes(gpu, rays: np.ndarray, want: np.ndarray, what: str = "") -> None:
+    """The closest hits of `rays` through every route of pt_trace_closest: one thread per
+    ray with its searches in place, and the kernels a render uses (queue regions, listed
+    searches, search_kernel, then the fused walk + bounce kernel or the separate walk kernel)."""
+    for route in ROUTES:
+        assert_hits_identical(gpu.trace_closest(rays, route=route), want, f"{what} [{route}]")
+
+
 def secondary_rays(hits: np.ndarray, rays: np.ndarray, seed: int) -> np.ndarray:
     """Bounce rays leaving the hit points of `hits` in random hemisphere directions,
     built like work_group.rs:42-46 (origin = point + dir * 1e-4, min = 1e-4)."""

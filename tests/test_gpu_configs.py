@@ -17,17 +17,55 @@ from tests import oracle_binding as ob
 pytestmark = pytest.mark.gpu
 
 
-def test_textured_scene_1080p_16spp(oracle):
-    """scene0.json (two textures, PBR spheres), 1920x1080, 16 samples, depth 8."""
-    scene = P.Scene.load(H.SCENE_DATA, "./scene0.json")
+def test_plumbing_config_256x256_4spp_against_the_literal_oracle(oracle):
+    """Benchmark configuration 1 at its own size: simple_scene.json (the cube behind a
+    transform, both textures, the emissive ceiling), 256x256, 4 samples, depth 8.  Bit for
+    bit against the oracle in portable-math mode; against the literal restatement (libm,
+    linear scan), whose paths branch differently after a last-place difference in sin/cos,
+    statistically: RMSE(gpu, ref) <= 1.5 x RMSE(ref seed A, ref seed B), frame means within
+    1 % (the sum over 65 k pixels x 4 samples)."""
+    scene = P.Scene.load(H.SCENE_DATA, "./simple_scene.json")
+    assert scene.desc.mesh_count == 1 and scene.desc.image_count == 2
+    gpu = P.HipRenderer.init(scene, 0)
+    cpu = oracle.scene(scene.desc_pointer)
+    task = H.load_task()
+    task.scene = "./simple_scene.json"
+    task.camera.resolution = [256, 256]
+    task.config = P.Config(trace_depth=8, iterations=4)
+    got = gpu.render(task, P.RenderOpts(seed=1))
+    same, st = cpu.render(task, P.RenderOpts(seed=1), accel=ob.ACCEL_LINEAR, math=ob.MATH_PORTABLE)
+    assert gpu.last_stats.rays == st.rays and np.array_equal(H.bits(got), H.bits(same))
+    ref_a, _ = cpu.render(task, P.RenderOpts(seed=1), accel=ob.ACCEL_LINEAR, math=ob.MATH_LIBM)
+    ref_b, _ = cpu.render(task, P.RenderOpts(seed=2), accel=ob.ACCEL_LINEAR, math=ob.MATH_LIBM)
+    noise = H.rmse(ref_a, ref_b)
+    assert H.rmse(got, ref_b) <= 1.5 * noise, (H.rmse(got, ref_b), noise)
+    assert abs(got.mean() - ref_b.mean()) <= 0.01 * ref_b.mean() + 2.0 * noise / np.sqrt(got.size)
+    gpu.close()
+    cpu.close()
+
+
+@pytest.mark.parametrize("scene_path", ["./simple_scene.json", "./scene0.json"])
+def test_textured_scene_1080p_16spp(oracle, scene_path):
+    """Benchmark configuration 2: 1920x1080, 16 samples, depth 8 on simple_scene.json --
+    the scene with both textures (mat3 = test_texture_1.png on the cube, mat2 =
+    test_texture_0.png on the walls) -- and, as a second case, on scene0.json (spheres and
+    planes, one texture, the PBR material)."""
+    scene = P.Scene.load(H.SCENE_DATA, scene_path)
+    if scene_path == "./simple_scene.json":
+        assert scene.desc.mesh_count == 1 and scene.desc.image_count == 2
     gpu = P.HipRenderer.init(scene, 0)
     task = H.load_task()
-    task.scene = "./scene0.json"
+    task.scene = scene_path
     task.camera.resolution = [1920, 1080]
     task.config = P.Config(trace_depth=8, iterations=16)
     full = gpu.render(task, P.RenderOpts(seed=1))
     assert gpu.last_stats.paths == 1920 * 1080 * 16
     assert np.array_equal(H.bits(full), H.bits(gpu.render(task, P.RenderOpts(seed=1)))), "render does not repeat"
+    # two batches in flight (a quarter of the frame's paths per batch) and one stream: the same bits
+    small = P.RenderOpts(seed=1, paths_per_batch=1920 * 1080 * 4)
+    assert np.array_equal(H.bits(full), H.bits(gpu.render(task, small)))
+    small.single_stream = True
+    assert np.array_equal(H.bits(full), H.bits(gpu.render(task, small)))
     # three row bands, as three ranks would render them, reassemble the frame bit for bit
     total = np.zeros_like(full)
     for rank in range(3):
@@ -42,11 +80,12 @@ def test_textured_scene_1080p_16spp(oracle):
     assert np.allclose((halves[0] + halves[1]) / 2, full, rtol=2e-6, atol=1e-7)
     # frame mean against the oracle (literal mode: libm, linear scan) at 1/64 of the pixels;
     # both estimate the same integral, tolerance 2 %
-    small = H.load_task()
-    small.camera.resolution = [240, 135]
-    small.config = P.Config(trace_depth=8, iterations=16)
+    small_task = H.load_task()
+    small_task.scene = scene_path
+    small_task.camera.resolution = [240, 135]
+    small_task.config = P.Config(trace_depth=8, iterations=16)
     cpu = oracle.scene(scene.desc_pointer)
-    ref, _ = cpu.render(small, P.RenderOpts(seed=2), accel=ob.ACCEL_LINEAR, math=ob.MATH_LIBM)
+    ref, _ = cpu.render(small_task, P.RenderOpts(seed=2), accel=ob.ACCEL_LINEAR, math=ob.MATH_LIBM)
     cpu.close()
     gpu.close()
     assert abs(full.mean() - ref.mean()) <= 0.02 * ref.mean()
@@ -109,7 +148,7 @@ def test_instanced_dragons_through_the_scene_graph(oracle, dragon_dir):
     rays = np.zeros((n, 8), dtype=np.float32)
     rays[:, :3], rays[:, 3:6], rays[:, 7] = src, d, H.F32_MAX
     want = cpu.trace(rays, accel=ob.ACCEL_BVH, math=ob.MATH_PORTABLE)
-    H.assert_hits_identical(gpu.trace_closest(rays), want, "instanced dragons")
+    H.assert_all_routes(gpu, rays, want, "instanced dragons")
     on_mesh = (want["hit"] == 1) & (want["tri_index"] != 0xFFFFFFFF)
     assert on_mesh.mean() > 0.2 and np.unique(want["node_index"][on_mesh]).size == 9
     # a small render through the wavefront pipeline, bit for bit
@@ -170,8 +209,7 @@ def test_flattened_instances_seven_million_triangles(oracle, dragon_dir):
     rays = np.zeros((n, 8), dtype=np.float32)
     rays[:, :3], rays[:, 3:6], rays[:, 7] = src, d, H.F32_MAX
     want = cpu.trace(rays, accel=ob.ACCEL_BVH, math=ob.MATH_PORTABLE)
-    got = gpu.trace_closest(rays)
-    H.assert_hits_identical(got, want, "flattened instances")
+    H.assert_all_routes(gpu, rays, want, "flattened instances")
     on_mesh = (want["hit"] == 1) & (want["tri_index"] != 0xFFFFFFFF)
     assert on_mesh.mean() > 0.2
     assert np.unique(want["tri_index"][on_mesh] // n1).size == 8  # every copy is hit

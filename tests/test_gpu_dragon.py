@@ -34,20 +34,18 @@ def test_dragon_closest_hit_parity(dragon):
     px = np.stack([rng.integers(0, 1920, n), rng.integers(0, 1080, n)], axis=1).astype(np.uint32)
     smp = rng.integers(0, 64, n).astype(np.uint64)
     rays = P.generate_rays(task.camera, 0, px, smp)
-    got = gpu.trace_closest(rays)
     want = cpu.trace(rays, accel=ob.ACCEL_BVH, math=ob.MATH_PORTABLE)
-    H.assert_hits_identical(got, want, "dragon primary vs oracle BVH")
+    H.assert_all_routes(gpu, rays, want, "dragon primary vs oracle BVH")
     on_mesh = (want["hit"] == 1) & (want["tri_index"] != 0xFFFFFFFF)
     assert on_mesh.mean() > 0.1
     sec = H.secondary_rays(want[on_mesh], rays[on_mesh], seed=6)
-    got2 = gpu.trace_closest(sec)
     want2 = cpu.trace(sec, accel=ob.ACCEL_BVH, math=ob.MATH_PORTABLE)
-    H.assert_hits_identical(got2, want2, "dragon secondary vs oracle BVH")
+    H.assert_all_routes(gpu, sec, want2, "dragon secondary vs oracle BVH")
     # the reference algorithm itself (every triangle tested) on a sample the CPU finishes in seconds
     k = 600
     sel = np.concatenate([rays[on_mesh][: k // 2], sec[: k // 2]])
     lin = cpu.trace(sel, accel=ob.ACCEL_LINEAR, math=ob.MATH_PORTABLE)
-    H.assert_hits_identical(gpu.trace_closest(sel), lin, "dragon vs oracle linear scan")
+    H.assert_all_routes(gpu, sel, lin, "dragon vs oracle linear scan")
     # and the GPU's own linear scan on a larger sample
     m = 20_000
     big = np.concatenate([rays[:m], sec[:m]])
@@ -77,7 +75,7 @@ def test_dragon_grazing_and_edge_rays(dragon):
     rays[:, :3], rays[:, 3:6], rays[:, 6], rays[:, 7] = src, d.astype(np.float32), 0.0, H.F32_MAX
     got = gpu.trace_closest(rays)
     H.assert_hits_identical(got, gpu.trace_closest(rays, brute_force=True), "edge/grazing rays: BVH vs scan")
-    H.assert_hits_identical(got, cpu.trace(rays, accel=ob.ACCEL_BVH, math=ob.MATH_PORTABLE), "edge/grazing vs oracle")
+    H.assert_all_routes(gpu, rays, cpu.trace(rays, accel=ob.ACCEL_BVH, math=ob.MATH_PORTABLE), "edge/grazing vs oracle")
 
 
 def test_dragon_render_bit_exact(dragon):
@@ -117,5 +115,5 @@ def test_dragon_rays_along_coordinate_planes(dragon):
     assert (rays[:, 3:6] == 0).any(axis=1).all()
     got = gpu.trace_closest(rays)
     H.assert_hits_identical(got, gpu.trace_closest(rays, brute_force=True), "axis-parallel rays: BVH vs scan")
-    H.assert_hits_identical(got, cpu.trace(rays, accel=ob.ACCEL_BVH, math=ob.MATH_PORTABLE), "axis-parallel rays vs oracle")
+    H.assert_all_routes(gpu, rays, cpu.trace(rays, accel=ob.ACCEL_BVH, math=ob.MATH_PORTABLE), "axis-parallel rays vs oracle")
     assert ((got["hit"] == 1) & (got["tri_index"] != 0xFFFFFFFF)).mean() > 0.5

@@ -111,13 +111,13 @@ def test_instance_run_against_the_oracle(oracle, tmp_path, monkeypatch, crowded)
     # closest hits: every candidate child searched by the lane that walks the scene graph
     rays = _rays(120_000, 17)
     want = cpu.trace(rays, accel=ob.ACCEL_LINEAR, math=ob.MATH_PORTABLE)
-    got = gpu.trace_closest(rays)
-    H.assert_hits_identical(got, want, "instance run, closest hits")
+    # ... and the same rays through the render's kernels: searches listed through the box tree
+    # and run ahead by search_kernel, the walk following each ray's chain of jobs
+    H.assert_all_routes(gpu, rays, want, "instance run, closest hits")
     on_mesh = (want["hit"] == 1) & (want["tri_index"] != 0xFFFFFFFF)
     assert np.unique(want["node_index"][on_mesh]).size >= (30 if not crowded else 10)
     sec = H.secondary_rays(want, rays, seed=5)[:60_000]
-    H.assert_hits_identical(gpu.trace_closest(sec), cpu.trace(sec, accel=ob.ACCEL_LINEAR, math=ob.MATH_PORTABLE),
-                            "instance run, secondary rays")
+    H.assert_all_routes(gpu, sec, cpu.trace(sec, accel=ob.ACCEL_LINEAR, math=ob.MATH_PORTABLE), "instance run, secondary rays")
     # renders: the searches listed through the box tree and run ahead of the walk
     task = H.load_task()
     task.camera.resolution = [96, 72]
@@ -134,7 +134,7 @@ def test_instance_run_against_the_oracle(oracle, tmp_path, monkeypatch, crowded)
     monkeypatch.setenv(RUN_MIN, "0")
     plain = P.HipRenderer.init(scene, 0)
     assert np.array_equal(H.bits(plain.render(task, P.RenderOpts(seed=4))), H.bits(ref))
-    H.assert_hits_identical(plain.trace_closest(rays), want, "children one after the other")
+    H.assert_all_routes(plain, rays, want, "children one after the other")
     plain.close()
     cpu.close()
 
@@ -156,7 +156,7 @@ def test_duplicate_children_first_one_wins(oracle, tmp_path, monkeypatch):
     cpu = oracle.scene(scene.desc_pointer)
     rays = H.random_rays(40_000, seed=3, origin_box=7.0, target_box=1.5)
     want = cpu.trace(rays, accel=ob.ACCEL_LINEAR, math=ob.MATH_PORTABLE)
-    H.assert_hits_identical(gpu.trace_closest(rays), want, "duplicates")
+    H.assert_all_routes(gpu, rays, want, "duplicates")
     hit = want["hit"] == 1
     mesh_nodes = [i for i, n in enumerate(scene.desc.nodes[: scene.desc.node_count]) if n.type == 2]
     assert (want["node_index"][hit] == mesh_nodes[2]).any() and not (want["node_index"][hit] == mesh_nodes[4]).any()

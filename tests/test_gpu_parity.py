@@ -52,14 +52,12 @@ def test_camera_rays_bit_exact(oracle):
 def test_closest_hit_primary_and_secondary(pair):
     name, gpu, cpu = pair
     rays = H.random_rays(200_000, seed=11, origin_box=8.0, target_box=3.5)
-    got = gpu.trace_closest(rays)
     want = cpu.trace(rays, accel=ob.ACCEL_LINEAR, math=ob.MATH_PORTABLE)
-    H.assert_hits_identical(got, want, f"{name} primary")
+    H.assert_all_routes(gpu, rays, want, f"{name} primary")
     assert want["hit"].mean() > 0.3
     sec = H.secondary_rays(want, rays, seed=12)
-    got2 = gpu.trace_closest(sec)
     want2 = cpu.trace(sec, accel=ob.ACCEL_LINEAR, math=ob.MATH_PORTABLE)
-    H.assert_hits_identical(got2, want2, f"{name} secondary")
+    H.assert_all_routes(gpu, sec, want2, f"{name} secondary")
     # the brute-force device path (linear scan like mesh/mod.rs:57-62) agrees too
     got3 = gpu.trace_closest(sec, brute_force=True)
     H.assert_hits_identical(got3, want2, f"{name} secondary brute")
@@ -73,7 +71,7 @@ def test_camera_rays_through_scene(pair, oracle):
     px = np.stack([rng.integers(0, 1024, n), rng.integers(0, 1024, n)], axis=1).astype(np.uint32)
     smp = rng.integers(0, 64, n).astype(np.uint64)
     rays = P.generate_rays(task.camera, 0, px, smp)
-    H.assert_hits_identical(gpu.trace_closest(rays), cpu.trace(rays, math=ob.MATH_PORTABLE), name)
+    H.assert_all_routes(gpu, rays, cpu.trace(rays, math=ob.MATH_PORTABLE), name)
 
 
 def test_material_sampling_bit_exact(pair):
@@ -176,7 +174,7 @@ def test_more_mesh_nodes_than_result_arrays(oracle, tmp_path, monkeypatch, run_m
     cpu = oracle.scene(scene.desc_pointer)
     rays = H.random_rays(100_000, seed=41, origin_box=9.0, target_box=6.0)
     want = cpu.trace(rays, accel=ob.ACCEL_LINEAR, math=ob.MATH_PORTABLE)
-    H.assert_hits_identical(gpu.trace_closest(rays), want, "twenty meshes")
+    H.assert_all_routes(gpu, rays, want, "twenty meshes")
     hit_nodes = np.unique(want["node_index"][(want["hit"] == 1) & (want["tri_index"] != 0xFFFFFFFF)])
     assert hit_nodes.size == 20
     task = H.load_task()

@@ -2,8 +2,8 @@
 of the 871k-triangle mesh as ONE mesh of 1.0e8 world-space triangles (a 5.8 GB
 search structure), 3840x2160.
 
-The copy count comes from PATHTRACING_AMD_FULL_SIZE_COPIES (default 24 = 2.1e7
-triangles, which keeps the default GPU suite short); 115 is the full size.
+The copy count comes from PATHTRACING_AMD_FULL_SIZE_COPIES (default 115, the full
+size: about two minutes on the GPU box; a smaller count shortens a local run).
 Checked through what does not need a CPU render of that size: closest hits
 against the oracle's own BVH over the same triangles, against the linear scan on
 the GPU and (a few rays) the oracle's linear scan, and a frame split into eight
@@ -26,7 +26,7 @@ from tests import oracle_binding as ob
 
 pytestmark = pytest.mark.gpu
 
-COPIES = int(os.environ.get("PATHTRACING_AMD_FULL_SIZE_COPIES", "24"))
+COPIES = int(os.environ.get("PATHTRACING_AMD_FULL_SIZE_COPIES", "115"))
 
 
 def _progress():
@@ -90,6 +90,8 @@ def test_flattened_instances_at_full_size(oracle, tmp_path):
     want = cpu.trace(rays, accel=ob.ACCEL_BVH, math=ob.MATH_PORTABLE)
     say("oracle BVH search done")
     H.assert_hits_identical(got, want, "flattened instances, oracle BVH")
+    for route in ("wavefront", "wavefront_split"):
+        H.assert_hits_identical(gpu.trace_closest(rays, route=route), want, f"flattened instances, oracle BVH [{route}]")
     # the linear scan: every lane walks all triangles, so the ray count does not matter much
     scan = gpu.trace_closest(rays[:1024], brute_force=True)
     say("GPU linear scan done")

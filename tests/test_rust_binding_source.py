@@ -95,7 +95,7 @@ def test_rust_structs_follow_the_header():
     header = _strip_comments(open(HEADER).read())
     crate = _strip_comments(open(CRATE).read())
     c, r = c_structs(header), rust_structs(crate)
-    assert len(c) == 16
+    assert len(c) == 17
     for name, fields in c.items():
         assert name in r, f"struct {name} is missing from the crate"
         assert r[name] == fields, f"struct {name}: header {fields} / crate {r[name]}"
