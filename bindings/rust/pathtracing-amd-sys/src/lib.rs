@@ -21,6 +21,7 @@ pub const PT_FLAG_PROFILE: u32 = 2;
 pub const PT_FLAG_WAVEFRONT: u32 = 4;
 pub const PT_FLAG_WAVEFRONT_SPLIT: u32 = 8;
 pub const PT_FLAG_SINGLE_STREAM: u32 = 16;
+pub const PT_STATIC_TRACE_MAX_RAYS: u32 = 16777216;
 
 /// `PtStatus`
 pub type PtStatus = c_int;
@@ -290,6 +291,14 @@ extern "C" {
         n: usize,
         flags: u32,
         out_hits: *mut PtHit,
+    ) -> PtStatus;
+    pub fn pt_trace_closest_device_static(
+        scene: *mut PtScene,
+        d_rays: *const PtRay,
+        n: usize,
+        flags: u32,
+        d_hits: *mut PtHit,
+        stream: *mut c_void,
     ) -> PtStatus;
     pub fn pt_generate_rays(
         camera: *const PtCamera,

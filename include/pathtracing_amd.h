@@ -289,6 +289,23 @@ typedef struct PtHit {
 PtStatus pt_trace_closest(PtScene* scene, const PtRay* rays, size_t n, uint32_t flags,
                           PtHit* out_hits);
 
+/* pt_trace_closest for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart
+ * in the reference.  d_rays and d_hits are device memory of the scene's device; the
+ * kernel's scratch (the per-lane columns that take the overflow of the BVH traversal
+ * stack and the saved frames of nested scene-graph nodes) is a static device array of
+ * 19.4 MB that every GPU the library runs on holds until the process ends, searched on
+ * a fixed grid of 64 blocks -- a quarter of the chip: for small, latency-bound queries.
+ * The call allocates and frees nothing, enqueues one kernel on `stream` (NULL: the
+ * default stream) and returns; n above PT_STATIC_TRACE_MAX_RAYS is
+ * PT_ERR_INVALID_ARGUMENT.  flags: PT_FLAG_BRUTE_FORCE or 0.  All calls on one GPU share
+ * the array: calls that overlap there (different streams, no ordering between them)
+ * race; calls on one stream are ordered.  Nothing in the array has to be cleared between
+ * calls (every entry is written before it is read). */
+#define PT_STATIC_TRACE_MAX_RAYS 16777216u
+PtStatus pt_trace_closest_device_static(PtScene* scene, const PtRay* d_rays, size_t n, uint32_t flags,
+                                        PtHit* d_hits, void* stream);
+
 /* Camera::get_ray (camera.rs:51-83) for `n` (pixel, sample) pairs, with the
  * library's counter-based random stream; host arrays.  pixel_xy holds n pairs
  * (x, y) in camera space. */

@@ -20,6 +20,7 @@ PT_FLAG_PROFILE = 2
 PT_FLAG_WAVEFRONT = 4
 PT_FLAG_WAVEFRONT_SPLIT = 8
 PT_FLAG_SINGLE_STREAM = 16
+PT_STATIC_TRACE_MAX_RAYS = 16777216
 
 NODE_COLLECTION, NODE_TRANSFORM, NODE_MESH, NODE_SPHERE, NODE_PLANE, NODE_KD_TREE = range(6)
 MATERIAL_BASE, MATERIAL_PBR = 0, 1
@@ -212,6 +213,7 @@ SYMBOLS = {
     ),
     "pt_resolve_device": (C.c_int, [_VOIDP, C.c_uint64, C.c_uint64, C.c_uint64, _VOIDP, _VOIDP]),
     "pt_trace_closest": (C.c_int, [_VOIDP, _VOIDP, C.c_size_t, C.c_uint32, _VOIDP]),
+    "pt_trace_closest_device_static": (C.c_int, [_VOIDP, _VOIDP, C.c_size_t, C.c_uint32, _VOIDP, _VOIDP]),
     "pt_generate_rays": (C.c_int, [C.POINTER(PtCamera), C.c_uint64, _VOIDP, _VOIDP, C.c_size_t, C.c_int, _VOIDP]),
     "pt_shade": (C.c_int, [_VOIDP, _VOIDP, _VOIDP, _VOIDP, C.c_uint64, C.c_size_t, _VOIDP, _VOIDP, _VOIDP]),
     "pt_host_scene_load": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(_VOIDP)]),

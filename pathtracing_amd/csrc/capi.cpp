@@ -1021,6 +1021,8 @@ PtStatus pt_scene_create(const PtSceneDesc* desc, int device, PtScene** out_scen
             s->run_slots = std::min<uint32_t>((uint32_t)run.children.size(), kRunSlotsPerRay);
         }
         hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        // set-up for pt_trace_closest_device_static: where this device keeps its copy of the static scratch array
+        hip_check(ptk::static_scratch_init(device), "hipGetSymbolAddress(scratch)");
         s->info.mesh_count = desc->mesh_count;
         s->info.bvh_bytes = s->bvh_bytes;
         s->info.instance_run_children = s->d.run.child_count;
@@ -1222,6 +1224,21 @@ PtStatus pt_trace_closest(PtScene* scene, const PtRay* rays, size_t n, uint32_t 
                       "trace_closest");
         stream_release(ds, 0, nullptr);
         hip_check(hipMemcpy(out_hits, d_hits.p, n * sizeof(PtHit), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+    });
+}
+
+PtStatus pt_trace_closest_device_static(PtScene* scene, const PtRay* d_rays, size_t n, uint32_t flags, PtHit* d_hits,
+                                        void* stream) {
+    return guarded([&] {
+        if (!scene || (n && (!d_rays || !d_hits))) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        if (flags & ~PT_FLAG_BRUTE_FORCE) throw Error(PT_ERR_INVALID_ARGUMENT, "pt_trace_closest_device_static takes PT_FLAG_BRUTE_FORCE only");
+        if (n > PT_STATIC_TRACE_MAX_RAYS)
+            throw Error(PT_ERR_INVALID_ARGUMENT, "pt_trace_closest_device_static: more than PT_STATIC_TRACE_MAX_RAYS (16777216) rays in one call");
+        if (n == 0) return;
+        DeviceGuard guard(scene->device);
+        hip_check(ptk::trace_closest_static(scene->device, scene->d, d_rays, n, (flags & PT_FLAG_BRUTE_FORCE) != 0, d_hits,
+                                            static_cast<hipStream_t>(stream)),
+                  "trace_closest_static");
     });
 }
 

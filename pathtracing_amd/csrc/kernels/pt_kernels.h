@@ -106,6 +106,18 @@ hipError_t frame_image(const float* d_sum, uint64_t pixels, float divisor, float
 hipError_t trace_closest(const DScene& scene, const PtRay* d_rays, size_t n, bool brute, PtHit* d_hits,
                          const Workspace& ws, hipStream_t stream);
 
+// trace_closest on a fixed grid of kStaticTraceBlocks blocks whose spill columns live in a
+// static device array: nothing is allocated, by this call or before it.  Every device
+// holds its own copy of the array; static_scratch_init looks its address up on the
+// current device (once per device, at set-up), and trace_closest_static fails with
+// hipErrorNotInitialized on a device where that has not happened.  All calls on one
+// device share the array: calls that overlap there race.
+constexpr uint32_t kStaticTraceBlocks = 64;
+hipError_t static_scratch_init(int device);
+size_t static_scratch_bytes();
+hipError_t trace_closest_static(int device, const DScene& scene, const PtRay* d_rays, size_t n, bool brute,
+                                PtHit* d_hits, hipStream_t stream);
+
 hipError_t generate_rays(const DCamera& cam, uint64_t seed, const uint32_t* d_pixel_xy, const uint64_t* d_sample,
                          size_t n, PtRay* d_rays, hipStream_t stream);
 

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 
 namespace ptk {
 
@@ -1271,6 +1272,50 @@ hipError_t trace_closest(const DScene& scene, const PtRay* d_rays, size_t n, boo
     if (n == 0) return hipSuccess;
     trace_closest_kernel<<<std::min(blocks_for(n), ws.persistent_blocks), kBlock, 0, stream>>>(
         scene, d_rays, n, brute ? 1u : 0u, d_hits, ws.spill, ws.persistent_blocks * kBlock);
+    return hipGetLastError();
+}
+
+// ---- closest hits without any allocation
+// The spill columns (traversal-stack overflow and the saved frames of nested scene-graph
+// nodes, see TravStack) of a grid of kStaticTraceBlocks blocks, 19.4 MB, held by every GPU
+// the library runs on until the process ends.  Nothing in it has to start at zero: a lane
+// writes an entry before it reads it.
+constexpr size_t kStaticScratchDwords = (size_t)kStaticTraceBlocks * kBlock * kSpillDwords;
+static __device__ __align__(256) uint32_t scratch[kStaticScratchDwords];
+
+namespace {
+constexpr int kMaxStaticDevices = 64;
+uint32_t* g_scratch_ptr[kMaxStaticDevices]; // per device: where that device's copy of `scratch` lives
+std::mutex g_scratch_mu;
+} // namespace
+
+size_t static_scratch_bytes() { return kStaticScratchDwords * sizeof(uint32_t); }
+
+hipError_t static_scratch_init(int device) {
+    if (device < 0 || device >= kMaxStaticDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[device]) return hipSuccess;
+    uint32_t* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!ptr) return hipErrorInvalidSymbol;
+    g_scratch_ptr[device] = ptr;
+    return hipSuccess;
+}
+
+hipError_t trace_closest_static(int device, const DScene& scene, const PtRay* d_rays, size_t n, bool brute,
+                                PtHit* d_hits, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    if (device < 0 || device >= kMaxStaticDevices) return hipErrorInvalidDevice;
+    uint32_t* ptr;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        ptr = g_scratch_ptr[device];
+    }
+    if (!ptr) return hipErrorNotInitialized;
+    const uint32_t blocks = std::min(blocks_for(n), kStaticTraceBlocks);
+    trace_closest_kernel<<<blocks, kBlock, 0, stream>>>(scene, d_rays, n, brute ? 1u : 0u, d_hits, ptr,
+                                                        kStaticTraceBlocks * kBlock);
     return hipGetLastError();
 }
 
