@@ -1,19 +1,30 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: path-traced frames of the dragon scene on MI355X.
+"""Benchmark of the hot path: path-traced frames on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c3|c4|c5]
 
-One step = one full render of the workload (1920x1080, 64 samples per pixel,
-trace depth 8, ~871k-triangle dragon stand-in) on every rank; ranks render
-disjoint sample ranges of the same frame and the un-normalised sums are reduced
-to rank 0 over RCCL inside the timed region (weak scaling: per-GPU work fixed).
+One step = one full render of the workload on every rank, the un-normalised sums
+reduced onto rank 0 over RCCL inside the timed region, rank 0 resolving the image.
 The scene is resident in HBM before timing starts.  Rank 0 prints one JSON line.
+
+  c3 (default)  dragon stand-in (871,200 triangles), 1920x1080, 64 samples per pixel per
+                GPU, depth 8; ranks take disjoint sample ranges (weak scaling)
+  c4            the same scene at 3840x2160, 256 samples in all, split into sample
+                ranges over the ranks (strong scaling)
+  c5            115 transformed instances of the mesh (1.0e8 triangles on screen) through
+                the scene graph, 3840x2160, 4 samples, split into row bands (strong scaling)
+
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts the N ranks
+itself (python -m torch.distributed.run, one process per GPU), relays rank 0's line and
+exits with the ranks' status; under torch.distributed.run it is one of the ranks.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -21,27 +32,60 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
+VALU_PEAK_PER_S = 256 * 4 * 2.4e9 / 2  # wave64 vector instructions per second: 1024 SIMD-32 units, 2 cycles each, 2.4 GHz
+DEPTH = 8
+CONFIGS = {
+    "c3": {"width": 1920, "height": 1080, "spp": 64, "mode": "samples", "scaling": "weak"},
+    "c4": {"width": 3840, "height": 2160, "spp": 256, "mode": "samples", "scaling": "strong"},
+    "c5": {"width": 3840, "height": 2160, "spp": 4, "mode": "rows", "scaling": "strong", "instances": 115},
+}
+HBM_REGIME_COPIES = 24  # flattened copies of the mesh for the HBM-bound record: 2.1e7 triangles, 1.2 GB of nodes and triangles
 
-import pathtracing_amd as P  # noqa: E402  (loads the HIP library; fails loudly if it is missing)
-from pathtracing_amd import synth  # noqa: E402
-from pathtracing_amd.distributed import render_sharded, shard_opts  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
-WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 64, 8
-
-
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (profiling runs)")
+    ap.add_argument("--no-hbm-regime", action="store_true", help="skip the second roofline record (flattened 2.1e7-triangle scene)")
     ap.add_argument("--rehearse", action="store_true",
                     help="N>1 on a box with fewer GPUs than ranks: every rank uses GPU 0, gloo instead of RCCL, the sum "
                          "staged through host memory; checks the control flow, its numbers mean nothing")
+    ap.add_argument("--stub-render", action="store_true",
+                    help="no GPU at all: the render is replaced by a stand-in that fills the buffer (tests of the launch and "
+                         "reduce logic on CPU; implies --rehearse)")
     ap.add_argument("--scene-dir", default=os.path.join(tempfile.gettempdir(), "pathtracing_amd_dragon"))
-    return ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.stub_render:
+        args.rehearse = True
+    return args
+
+
+def self_launch(args) -> int:
+    """Starts the ranks as fresh processes (nothing in this process has touched the GPU:
+    only the standard library is imported so far), relays rank 0's JSON line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        try:
+            if "metric" in json.loads(ln):
+                line = ln
+        except ValueError:
+            sys.stderr.write(ln + "\n")
+    if line is not None:
+        print(line, flush=True)
+    if proc.returncode == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks printed no result line\n")
+        return 1
+    return proc.returncode
 
 
 def host_threads() -> int:
@@ -52,68 +96,160 @@ def host_threads() -> int:
     return max(1, min(os.cpu_count() or 1, 16))
 
 
-def cpu_legs(scene: P.Scene, task: P.RenderTask):
-    """The oracle on the host cores: (a) the reference algorithm (every triangle
-    tested) on a small crop, (b) its BVH mode on a larger sample, which also
-    measures the per-ray statistics of the algorithmic byte count."""
+def cpu_legs(P, scene, task):
+    """The oracle on the host cores: (a) the reference algorithm (every triangle tested)
+    on a small crop, (b) its BVH mode on a larger sample."""
     from tests import oracle_binding as ob  # test infrastructure: checker / baseline only
 
     oracle = ob.load()
     osc = oracle.scene(scene.desc_pointer)
     threads = host_threads()
-    # (b) BVH mode, 480x270, 1 sample
     t = P.RenderTask(scene=task.scene, config=P.Config(DEPTH, 1), camera=P.Camera(**{**task.camera.__dict__}))
     t.camera.resolution = [480, 270]
     _, st = osc.render(t, P.RenderOpts(seed=0), accel=ob.ACCEL_BVH, math=ob.MATH_LIBM, threads=threads)
-    stats = {
-        "n_box": st.box_tests / st.rays,
-        "n_tri": st.tri_tests / st.rays,
-        "hit_fraction": st.hits / st.rays,
-        "texture_fraction": st.tex_fetches / st.rays,
-        "mean_path_length": st.rays / st.paths,
-        "sample_rays": int(st.rays),
-    }
     bvh = {"value": st.rays / st.seconds / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-           "sample": "oracle in BVH mode, same scene and camera at 480x270, 1 sample per pixel, depth 8"}
-    # (a) linear scan, 32x18, 1 sample
+           "sample": f"oracle in BVH mode (its own BVH2), same scene and camera at 480x270, 1 sample per pixel, depth 8: "
+                     f"{int(st.rays)} rays in {st.seconds * 1e3:.0f} ms"}
     t.camera.resolution = [32, 18]
     _, st2 = osc.render(t, P.RenderOpts(seed=0), accel=ob.ACCEL_LINEAR, math=ob.MATH_LIBM, threads=threads)
     ref = {"value": st2.rays / st2.seconds / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
            "sample": f"oracle running the reference algorithm (linear scan of all 871,200 triangles per ray), same scene "
                      f"and camera at 32x18, 1 sample per pixel, depth 8: {int(st2.rays)} rays in {st2.seconds:.1f} s"}
     osc.close()
-    return ref, bvh, stats
+    return ref, bvh
 
 
-def bytes_per_ray(s) -> float:
-    """Algorithmic HBM bytes of one path segment: 32 B per box test (bounds +
-    topology), 36 B per triangle test (nine f32 positions), 60 B of shading data
-    per hit, 4 B per texel, 128 B of queue traffic (48 B ray record and 16 B of
-    hit state, each written and read once), and the 12 B accumulator
-    read-modify-write per path spread over its segments."""
-    return (32.0 * s["n_box"] + 36.0 * s["n_tri"] + 60.0 * s["hit_fraction"] + 4.0 * s["texture_fraction"] + 128.0
-            + 24.0 / s["mean_path_length"])
+def search_kernel_record(P, renderer, task, opts_base, accum_ptr, stream):
+    """The dominant kernel measured live: one render with events around every search_kernel
+    launch (durations) and one with the kernel counting the records it fetches (bytes).
+    Algorithmic bytes of a launch, as the kernel's data layout has them: one 64-B node record
+    per node visited (four child boxes), one 48-B triangle record per triangle tested, and
+    per search the 48-B job read and the 16-B result written."""
+    o = P.RenderOpts(**opts_base.__dict__)
+    o.profile = True
+    prof = renderer.render_accumulate_device(task, o, accum_ptr, stream, want_stats=True)
+    o = P.RenderOpts(**opts_base.__dict__)
+    o.count_visits = True
+    o.single_stream = True
+    cnt = renderer.render_accumulate_device(task, o, accum_ptr, stream, want_stats=True)
+    launches = int(prof.search_kernel_launches)
+    if launches == 0 or cnt.searches == 0:
+        return None
+    launch_ms = prof.search_kernel_ms / launches
+    bytes_per_launch = (64.0 * cnt.node_visits + 48.0 * cnt.triangle_tests + 64.0 * cnt.searches) / launches
+    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+    return {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": None, "kernel": "search_kernel", "bytes_per_launch": bytes_per_launch, "launch_ms": launch_ms,
+        "launches": launches, "searches_per_launch": cnt.searches / launches,
+        "node_visits_per_search": cnt.node_visits / cnt.searches, "triangle_tests_per_search": cnt.triangle_tests / cnt.searches,
+        "bytes_per_search": bytes_per_launch * launches / cnt.searches,
+        "searches_per_ray": cnt.searches / cnt.rays, "search_kernel_share_of_render": prof.search_kernel_ms / prof.render_ms,
+        "searches_per_s_in_kernel": cnt.searches / (prof.search_kernel_ms * 1e-3),
+        "bvh_bytes": int(cnt.bvh_bytes), "render_ms_profiled": prof.render_ms,
+    }
 
 
-def search_bytes_per_ray(s, searches_per_ray: float) -> float:
-    """The share of bytes_per_ray() that the BVH search kernel moves: the box and
-    triangle tests of a ray, and per search the 48 B request it reads and the
-    16 B result it writes."""
-    return 32.0 * s["n_box"] + 36.0 * s["n_tri"] + 64.0 * searches_per_ray
+def recorded(name):
+    """A measurement that cannot be taken inside this process (rocprofv3 PMC passes), as
+    recorded under profiles/ by tools/collect_profiles.sh."""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def hbm_regime_record(P, N, synth, scene_dir, device, torch):
+    """The same kernel where it is bound by memory: HBM_REGIME_COPIES transformed copies of the
+    mesh flattened into ONE mesh (2.1e7 world-space triangles, 1.2 GB of nodes and triangles,
+    five times the Infinity Cache), 3840x2160, 2 samples per pixel."""
+    import ctypes as C
+
+    import numpy as np
+
+    with open(os.path.join(scene_dir, "flattened.json"), "w") as f:
+        json.dump(synth.flattened_scene_json(), f)
+    with open(os.path.join(scene_dir, "dragon_task.json")) as f:
+        task = P.RenderTask.from_json(f.read())
+    task.scene = "./flattened.json"
+    task.camera.resolution = [3840, 2160]
+    task.camera.position = [0.0, 0.0, 330.0]
+    task.camera.focal_length = 330.0
+    task.config = P.Config(trace_depth=DEPTH, iterations=2)
+    scene = P.Scene.load(scene_dir, task.scene)
+    base = scene.desc
+    n1 = int(base.meshes[0].triangle_count)
+    one = np.ctypeslib.as_array(base.meshes[0].positions, shape=(n1, 9))
+    positions = synth.flattened_copies(one, HBM_REGIME_COPIES, seed=5)
+    mesh = N.PtMeshDesc()
+    mesh.triangle_count = positions.shape[0]
+    mesh.positions = positions.ctypes.data_as(C.POINTER(C.c_float))
+    big = N.PtSceneDesc()
+    for name, _ in N.PtSceneDesc._fields_:
+        setattr(big, name, getattr(base, name))
+    big.meshes = C.pointer(mesh)
+    big.mesh_count = 1
+    t0 = time.time()
+    gpu = P.HipRenderer.from_desc(C.pointer(big), device)
+    setup_s = time.time() - t0
+    accum = torch.zeros(3840 * 2160 * 3, dtype=torch.float32, device=f"cuda:{device}")
+    stream = torch.cuda.current_stream().cuda_stream
+    gpu.render_accumulate_device(task, P.RenderOpts(seed=0), accum.data_ptr(), stream, want_stats=True)  # warm-up
+    rec = search_kernel_record(P, gpu, task, P.RenderOpts(seed=0), accum.data_ptr(), stream)
+    timed = gpu.render_accumulate_device(task, P.RenderOpts(seed=0), accum.data_ptr(), stream, want_stats=True)
+    gpu.close()
+    if rec is None:
+        return None
+    rec["workload"] = (f"{HBM_REGIME_COPIES} transformed copies of the mesh flattened into one mesh of {positions.shape[0]} "
+                       f"world-space triangles, 3840x2160, 2 samples per pixel, depth {DEPTH}")
+    rec["mrays_per_s"] = timed.rays / timed.render_ms / 1e3
+    rec["scene_setup_s"] = setup_s
+    t = recorded("hbm_traffic_flattened.json")
+    rec["traffic"] = t.get("bytes_per_launch") if t else None
+    return rec
+
+
+class StubRenderer:
+    """Stands in for the GPU in tests of the launch / shard / reduce logic: every sample
+    adds 1 to every pixel of the rows it covers."""
+
+    def __init__(self, width, height):
+        self.width, self.height = width, height
+
+    def render_accumulate(self, task, opts, buf):
+        import types
+
+        x0, y0, w, h = opts.tile if opts.tile else (0, 0, self.width, self.height)
+        view = buf.view(self.height, self.width, 3)
+        view[y0:y0 + h, x0:x0 + w, :] += float(task.config.iterations)
+        paths = task.config.iterations * w * h
+        return types.SimpleNamespace(rays=paths, paths=paths, searches=0, render_ms=0.0)
 
 
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     multi = world > 1
-    if multi and args.gpus != world:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not multi and args.gpus != 1:
-        raise SystemExit("launch N>1 through torch.distributed.run (one process per GPU)")
 
+    import numpy as np  # noqa: F401
     import torch  # device buffers, streams and the RCCL reduce; not on the compute path
+
+    import pathtracing_amd as P  # loads the HIP library; fails loudly if it is missing
+    from pathtracing_amd import _native as N
+    from pathtracing_amd import synth
+    from pathtracing_amd.distributed import render_sharded, shard_opts
+
+    cfg = dict(CONFIGS[args.config])
+    if args.stub_render:
+        cfg.update(width=64, height=40, spp=8 if cfg["scaling"] == "strong" else 2)
+    width, height, spp = cfg["width"], cfg["height"], cfg["spp"]
 
     if multi:
         import torch.distributed as dist
@@ -123,140 +259,157 @@ def main():
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus, "the process group does not have one rank per requested GPU"
     device = local_rank if multi and not args.rehearse else 0
-    torch.cuda.set_device(device)
+    tdev = "cpu" if args.stub_render else f"cuda:{device}"
+    if not args.stub_render:
+        torch.cuda.set_device(device)
 
-    # scene files: rank 0 of the node writes them, the others wait
-    if local_rank == 0:
-        task_path = synth.write_dragon_scene(args.scene_dir, os.path.join(ROOT, "scene_data"))
-    if multi:
-        dist.barrier()
-    task_path = os.path.join(args.scene_dir, "dragon_task.json")
-    with open(task_path) as f:
-        task = P.RenderTask.from_json(f.read())
-    task.camera.resolution = [WIDTH, HEIGHT]
-    task.config = P.Config(trace_depth=DEPTH, iterations=SPP)
-    scene = P.Scene.load(args.scene_dir, task.scene)
-    t0 = time.time()
-    renderer = P.HipRenderer.init(scene, device)  # BVH build + upload: outside the timed region
-    setup_s = time.time() - t0
+    # ---- the scene: rank 0 of the node writes the files, the others wait; every rank uploads its own copy
+    setup_s, scene, renderer, info = 0.0, None, None, None
+    if args.stub_render:
+        task = P.RenderTask.from_json(json.dumps(synth.dragon_render_task()))
+        renderer = StubRenderer(width, height)
+    else:
+        if local_rank == 0:
+            synth.write_dragon_scene(args.scene_dir, os.path.join(ROOT, "scene_data"))
+            if args.config == "c5":
+                with open(os.path.join(args.scene_dir, "instanced.json"), "w") as f:
+                    json.dump(synth.instanced_dragon_scene_json(cfg["instances"], seed=3), f)
+        if multi:
+            dist.barrier()
+        with open(os.path.join(args.scene_dir, "dragon_task.json")) as f:
+            task = P.RenderTask.from_json(f.read())
+        if args.config == "c5":
+            task.scene = "./instanced.json"
+            task.camera.position = [0.0, 10.0, 110.0]
+            task.camera.focal_length = 110.0
+        scene = P.Scene.load(args.scene_dir, task.scene)
+        t0 = time.time()
+        renderer = P.HipRenderer.init(scene, device)  # BVH build (or .tree adoption) + upload: outside the timed region
+        setup_s = time.time() - t0
+        info = renderer.info
+    task.camera.resolution = [width, height]
 
-    accum = torch.zeros(HEIGHT * WIDTH * 3, dtype=torch.float32, device=f"cuda:{device}")
-    out = torch.empty_like(accum)
-    stream = torch.cuda.current_stream().cuda_stream
-    # weak scaling: the frame gets SPP samples per GPU; rank r renders samples [r*SPP, (r+1)*SPP)
+    # weak scaling: every GPU renders `spp` samples of the frame (world * spp in all); strong: `spp` in all
+    total_spp = spp * world if cfg["scaling"] == "weak" else spp
     frame = P.RenderTask(scene=task.scene, scene_md5=task.scene_md5, camera=task.camera,
-                         config=P.Config(trace_depth=DEPTH, iterations=SPP * world))
+                         config=P.Config(trace_depth=DEPTH, iterations=total_spp))
+    accum = torch.zeros(height * width * 3, dtype=torch.float32, device=tdev)
+    out = torch.empty_like(accum)
+    stream = 0 if args.stub_render else torch.cuda.current_stream().cuda_stream
     last = {}
+
+    def render(sub, opts, buf):
+        if args.stub_render:
+            last["stats"] = renderer.render_accumulate(sub, opts, buf)
+        else:
+            last["stats"] = renderer.render_accumulate_device(sub, opts, buf.data_ptr(), stream, want_stats=True)
 
     def step():
         accum.zero_()
-
-        def render(sub, opts, buf):
-            last["stats"] = renderer.render_accumulate_device(sub, opts, buf.data_ptr(), stream, want_stats=True)
-
-        # renders, then RCCL reduce(sum) onto rank 0
-        render_sharded(render, frame, accum, mode="samples", seed=0, stage_on_host=args.rehearse)
+        last["stats"] = None
+        # this rank's share, then the sum of all ranks' buffers onto rank 0 (RCCL reduce), then get_image on rank 0
+        render_sharded(render, frame, accum, mode=cfg["mode"], seed=0, stage_on_host=args.rehearse and not args.stub_render)
         if rank == 0:
-            P._native.check(P._native.lib.pt_resolve_device(accum.data_ptr(), WIDTH, HEIGHT, SPP * world, out.data_ptr(), stream))
+            if args.stub_render:
+                out.copy_(accum * (1.0 / total_spp))
+            else:
+                N.check(N.lib.pt_resolve_device(accum.data_ptr(), width, height, total_spp, out.data_ptr(), stream))
         return last["stats"]
 
     def fence():
         if multi:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not args.stub_render:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
     fence()
     t0 = time.perf_counter()
-    rays = 0
+    rays = searches = 0
     for _ in range(args.steps):
-        rays += step().rays
+        st = step()
+        if st is not None:
+            rays += st.rays
+            searches += st.searches
     fence()
     elapsed = time.perf_counter() - t0
+    devices = [device]
     if multi:
-        scalar_device = "cpu" if args.rehearse else f"cuda:{device}"
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=scalar_device)
+        sdev = "cpu" if args.rehearse else f"cuda:{device}"
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=sdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        total = torch.tensor([rays], dtype=torch.int64, device=scalar_device)
+        total = torch.tensor([rays, searches], dtype=torch.int64, device=sdev)
         dist.all_reduce(total, op=dist.ReduceOp.SUM)
-        rays = int(total.item())
+        rays, searches = int(total[0].item()), int(total[1].item())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, device)
+        devices = gathered
 
     result = None
     if rank == 0:
         frame_mean = float(out.mean().item())
-        # one more, untimed, render of this rank's share (no collective: the other ranks
-        # have left the loop) with events around every search_kernel launch
-        sub, o = shard_opts(frame, world, 0, "samples", seed=0)
-        o.profile = True
-        prof = renderer.render_accumulate_device(sub, o, accum.data_ptr(), stream, want_stats=True)
-        torch.cuda.synchronize()
-        if args.no_cpu_baseline:
-            ref, bvh, stats = None, None, None
-        elif multi:
-            # the CPU legs run at N = 1 only; the per-ray statistics of the workload do not
-            # depend on N and are taken from the record of an N = 1 run
-            ref, bvh, stats = None, None, recorded_ray_statistics()
-        else:
-            ref, bvh, stats = cpu_legs(scene, task)
-        roofline = None
-        if stats is not None and prof.search_kernel_launches:
-            # dominant kernel: search_kernel (one launch per path segment and mesh node)
-            b_search = search_bytes_per_ray(stats, prof.searches / prof.rays)
-            launch_ms = prof.search_kernel_ms / prof.search_kernel_launches
-            rays_per_launch = prof.rays / prof.search_kernel_launches
-            achieved = b_search * rays_per_launch / (launch_ms * 1e-3) / 1e9
-            b_ray = bytes_per_ray(stats)
-            roofline = {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(), "kernel": "search_kernel",
-                "bytes_per_ray": b_search, "rays_per_launch": rays_per_launch, "launch_ms": launch_ms,
-                "launches": int(prof.search_kernel_launches), "searches_per_ray": prof.searches / prof.rays,
-                "ray_statistics": stats,
-                # all kernels of the render against all algorithmic bytes of a path segment
-                "whole_render": {"bytes_per_ray": b_ray, "achieved": b_ray * prof.rays / (prof.render_ms * 1e-3) / 1e9,
-                                 "frac": b_ray * prof.rays / (prof.render_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "render_ms": prof.render_ms},
-            }
+        roofline = hbm_regime = ref = bvh = None
+        if not args.stub_render:
+            # untimed: this rank's share once more (no collective: the other ranks have left the loop), with
+            # events around every search_kernel launch, and once with the kernel counting what it fetches
+            sub, o = shard_opts(frame, world, 0, cfg["mode"], seed=0)
+            roofline = search_kernel_record(P, renderer, sub, o, accum.data_ptr(), stream)
+            torch.cuda.synchronize()
+            if roofline is not None:
+                t = recorded("hbm_traffic.json") if args.config == "c3" else None
+                roofline["traffic"] = t.get("bytes_per_launch") if t else None
+                # the working set (nodes + leaf triangles) against the 256 MiB Infinity Cache: below it the records are
+                # re-read from cache and the figure above is a rate of cache traffic, bounded by the HBM peak only by name
+                roofline["cache_resident"] = roofline["bvh_bytes"] < 256 * 2**20
+                sq = recorded("sq_counters.json") if args.config == "c3" else None
+                if sq and sq.get("search_kernel"):
+                    k = sq["search_kernel"]
+                    insts = k["valu_insts_per_launch"]
+                    roofline["issue"] = {"bound": "valu", "achieved": insts / (roofline["launch_ms"] * 1e-3), "peak": VALU_PEAK_PER_S,
+                                         "unit": "wave64 VALU instructions/s",
+                                         "frac": insts / (roofline["launch_ms"] * 1e-3) / VALU_PEAK_PER_S,
+                                         "active_lane_share": k.get("active_lane_share"), "source": "profiles/sq_counters.json"}
+            if not multi and args.config == "c3":
+                if not args.no_hbm_regime:
+                    hbm_regime = hbm_regime_record(P, N, synth, args.scene_dir, device, torch)
+                if not args.no_cpu_baseline:
+                    ref, bvh = cpu_legs(P, scene, task)
+        per_gpu = " per GPU" if cfg["scaling"] == "weak" else ""
+        workloads = {
+            "c3": f"dragon stand-in (871,200 triangles, torus-knot tube) in a textured box, {width}x{height}, {spp} samples per "
+                  f"pixel{per_gpu}, trace depth {DEPTH}",
+            "c4": f"dragon stand-in (871,200 triangles) in a textured box, {width}x{height}, {spp} samples per pixel in all, "
+                  f"trace depth {DEPTH}",
+            "c5": f"{cfg.get('instances')} transformed instances of the 871,200-triangle mesh through the scene graph "
+                  f"(1.0e8 triangles on screen), {width}x{height}, {spp} samples per pixel in all, trace depth {DEPTH}",
+        }
+        split = {"samples": "sample range per GPU", "rows": "band of 8-pixel rows per GPU"}[cfg["mode"]]
         result = {
-            "metric": "Mrays/s dragon 1080p 64spp", "value": rays / elapsed / 1e6, "unit": "Mrays/s",
+            "metric": "Mrays/s dragon 1080p 64spp" if args.config == "c3" else f"Mrays/s {args.config}",
+            "value": rays / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"dragon stand-in (871,200 triangles, torus-knot tube) in a textured box, {WIDTH}x{HEIGHT}, "
-                            f"{SPP} samples per pixel per GPU, trace depth {DEPTH}",
-                "sharding": ("REHEARSAL on one GPU (gloo, host-staged sum): not a measurement" if args.rehearse else
-                             "sample range per GPU, RCCL reduce(sum) of the accumulation buffers onto rank 0") if multi else "single GPU",
-                "rays_per_step": rays // args.steps, "scene_setup_s": setup_s, "frame_mean": frame_mean,
+                "workload": ("STAND-IN RENDER (no GPU): launch and reduce logic only; " if args.stub_render else "") + workloads[args.config],
+                "sharding": (("REHEARSAL (gloo, host-staged sum): not a measurement; " if args.rehearse else "")
+                             + f"{split}, RCCL reduce(sum) of the accumulation buffers onto rank 0") if multi else "single GPU",
+                "ranks": world, "devices": devices,
+                "rays_per_step": rays // max(args.steps, 1), "searches_per_step": searches // max(args.steps, 1),
+                "searches_per_s": searches / elapsed, "scene_setup_s": setup_s,
+                "trees_adopted": int(info.trees_adopted) if info else None, "bvh_build_s": info.build_ms / 1e3 if info else None,
+                "frame_mean": frame_mean,
             },
-            "roofline": roofline, "cpu_baseline": ref, "cpu_baseline_bvh": bvh,
+            "roofline": roofline, "roofline_hbm_regime": hbm_regime, "cpu_baseline": ref, "cpu_baseline_bvh": bvh,
         }
     if multi:
         dist.barrier()
         dist.destroy_process_group()
     if result is not None:
         print(json.dumps(result), flush=True)
-
-
-def recorded_ray_statistics():
-    try:
-        with open(os.path.join(ROOT, "profiles", "ray_statistics.json")) as f:
-            return json.load(f).get("ray_statistics")
-    except (OSError, ValueError):
-        return None
-
-
-def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes, when a
-    measurement for this workload has been recorded under profiles/."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get("bytes_per_launch")
-    except (OSError, ValueError):
-        return None
 
 
 if __name__ == "__main__":

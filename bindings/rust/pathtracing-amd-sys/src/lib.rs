@@ -14,13 +14,14 @@
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const PT_ABI_VERSION: u32 = 1;
+pub const PT_ABI_VERSION: u32 = 2;
 pub const PT_NO_INDEX: u32 = 0xFFFF_FFFF;
 pub const PT_FLAG_BRUTE_FORCE: u32 = 1;
 pub const PT_FLAG_PROFILE: u32 = 2;
 pub const PT_FLAG_WAVEFRONT: u32 = 4;
 pub const PT_FLAG_WAVEFRONT_SPLIT: u32 = 8;
 pub const PT_FLAG_SINGLE_STREAM: u32 = 16;
+pub const PT_FLAG_COUNT_VISITS: u32 = 32;
 pub const PT_STATIC_TRACE_MAX_RAYS: u32 = 16777216;
 
 /// `PtStatus`
@@ -222,6 +223,8 @@ pub struct PtRenderStats {
     pub searches: u64,
     pub search_kernel_ms: f64,
     pub search_kernel_launches: u64,
+    pub node_visits: u64,
+    pub triangle_tests: u64,
 }
 
 #[repr(C)]

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 1u
+#define PT_ABI_VERSION 2u
 
 /* ------------------------------------------------------------------ status */
 
@@ -224,6 +224,9 @@ typedef struct PtRenderTask {
 #define PT_FLAG_WAVEFRONT_SPLIT 8u /* the same, with the separate walk kernel even where a
                                   render would use the fused walk + bounce kernel              */
 #define PT_FLAG_SINGLE_STREAM 16u /* render: never keep two batches in flight                  */
+#define PT_FLAG_COUNT_VISITS 32u /* render: the BVH search kernel counts the node and triangle
+                                  records it fetches (PtRenderStats.node_visits,
+                                  .triangle_tests); a little slower                            */
 
 /* Knobs the reference does not have.  A NULL pointer means all zero. */
 typedef struct PtRenderOpts {
@@ -244,6 +247,8 @@ typedef struct PtRenderStats {
     double search_kernel_ms;         /* PT_FLAG_PROFILE: summed duration of the BVH search
                                         kernel launches                                        */
     uint64_t search_kernel_launches; /* PT_FLAG_PROFILE: how many launches that sum covers    */
+    uint64_t node_visits;    /* PT_FLAG_COUNT_VISITS: 64-byte node records the searches fetched */
+    uint64_t triangle_tests; /* PT_FLAG_COUNT_VISITS: 48-byte triangle records they tested      */
 } PtRenderStats;
 
 /* Renderer::render (renderer/mod.rs:12) -> Rgb32FImage: fills out_rgb

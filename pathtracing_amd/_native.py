@@ -20,6 +20,7 @@ PT_FLAG_PROFILE = 2
 PT_FLAG_WAVEFRONT = 4
 PT_FLAG_WAVEFRONT_SPLIT = 8
 PT_FLAG_SINGLE_STREAM = 16
+PT_FLAG_COUNT_VISITS = 32
 PT_STATIC_TRACE_MAX_RAYS = 16777216
 
 NODE_COLLECTION, NODE_TRANSFORM, NODE_MESH, NODE_SPHERE, NODE_PLANE, NODE_KD_TREE = range(6)
@@ -180,6 +181,8 @@ class PtRenderStats(C.Structure):
         ("searches", C.c_uint64),
         ("search_kernel_ms", C.c_double),
         ("search_kernel_launches", C.c_uint64),
+        ("node_visits", C.c_uint64),
+        ("triangle_tests", C.c_uint64),
     ]
 
 

@@ -105,13 +105,15 @@ class RenderOpts:
     paths_per_batch: int = 0
     profile: bool = False  # time each BVH search kernel launch (RenderStats.search_kernel_ms)
     single_stream: bool = False  # never keep two batches in flight
+    count_visits: bool = False  # count the node / triangle records the search kernel fetches (RenderStats)
 
     def to_native(self) -> N.PtRenderOpts:
         o = N.PtRenderOpts()
         o.seed = self.seed
         o.sample_offset = self.sample_offset
         o.flags = ((N.PT_FLAG_BRUTE_FORCE if self.brute_force else 0) | (N.PT_FLAG_PROFILE if self.profile else 0)
-                   | (N.PT_FLAG_SINGLE_STREAM if self.single_stream else 0))
+                   | (N.PT_FLAG_SINGLE_STREAM if self.single_stream else 0)
+                   | (N.PT_FLAG_COUNT_VISITS if self.count_visits else 0))
         if self.tile is not None:
             o.tile_x0, o.tile_y0, o.tile_w, o.tile_h = (int(v) for v in self.tile)
         o.paths_per_batch = self.paths_per_batch

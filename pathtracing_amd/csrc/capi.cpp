@@ -90,6 +90,8 @@ struct DeviceState {
 
 namespace {
 
+constexpr int kTotals = 4; // Workspace::ray_total: rays, searches, node records fetched, triangle records fetched
+
 DeviceState& device_state(int device) {
     static std::mutex registry_mu;
     static std::map<int, DeviceState*>* registry = new std::map<int, DeviceState*>(); // never destroyed: the HIP
@@ -170,7 +172,7 @@ void ensure_trace_state(DeviceState& ds, int k) {
         for (int q = 0; q < 2; q++)
             hip_check(hipMalloc(reinterpret_cast<void**>(&ws.wave_counts[q]), waves * sizeof(uint32_t)), "hipMalloc counts");
         hip_check(hipMalloc(reinterpret_cast<void**>(&ws.job_counts), waves * sizeof(uint32_t)), "hipMalloc counts");
-        hip_check(hipMalloc(reinterpret_cast<void**>(&ws.ray_total), 2 * sizeof(uint64_t)), "hipMalloc ray_total");
+        hip_check(hipMalloc(reinterpret_cast<void**>(&ws.ray_total), kTotals * sizeof(uint64_t)), "hipMalloc ray_total");
     } catch (...) {
         free_trace_state(ws);
         throw;
@@ -723,6 +725,7 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
     std::lock_guard<std::mutex> lock(ds.mu);
     const bool brute = (o.flags & PT_FLAG_BRUTE_FORCE) != 0;
     const bool profile = stats && (o.flags & PT_FLAG_PROFILE) != 0;
+    const bool count_visits = stats && (o.flags & PT_FLAG_COUNT_VISITS) != 0;
     // Path slots per batch.  Bigger batches are faster (fewer launches whose last waves run alone, more
     // samples of a pixel block next to each other); a slot costs about 210 bytes of queues, nine times
     // the job records on top for scenes with an instance run.  The default is halved until it fits.
@@ -796,8 +799,8 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
         events.push_back(e);
         hip_check(hipEventCreate(&e), "hipEventCreate");
         events.push_back(e);
-        hip_check(hipMemsetAsync(ds.ws[0].ray_total, 0, 2 * sizeof(uint64_t), stream), "hipMemsetAsync");
-        if (two) hip_check(hipMemsetAsync(ds.ws[1].ray_total, 0, 2 * sizeof(uint64_t), ds.side), "hipMemsetAsync");
+        hip_check(hipMemsetAsync(ds.ws[0].ray_total, 0, kTotals * sizeof(uint64_t), stream), "hipMemsetAsync");
+        if (two) hip_check(hipMemsetAsync(ds.ws[1].ray_total, 0, kTotals * sizeof(uint64_t), ds.side), "hipMemsetAsync");
         hip_check(hipEventRecord(events[0], stream), "hipEventRecord");
     }
     uint64_t paths = 0, batch_index = 0;
@@ -819,7 +822,7 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
             if (k == 1 && side_holds_contrib) hip_check(hipStreamWaitEvent(ds.side, ds.accumulated, 0), "hipStreamWaitEvent");
             hip_check(ptk::render_batch(scene->d, cam, g, o.seed, o.sample_offset + s, cnt, (uint32_t)task->trace_depth,
                                         brute, scene->targets, scene->run_slots, ds.ws[k], st,
-                                        profile ? &seg_events : nullptr),
+                                        profile ? &seg_events : nullptr, count_visits),
                       "render_batch");
             if (k == 1) {
                 hip_check(hipEventRecord(ds.side_done, ds.side), "hipEventRecord");
@@ -842,18 +845,19 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
         hip_check(hipEventSynchronize(events[1]), "hipEventSynchronize");
         float ms = 0.0f;
         hip_check(hipEventElapsedTime(&ms, events[0], events[1]), "hipEventElapsedTime");
-        uint64_t totals[2] = {0, 0};
+        uint64_t totals[kTotals] = {0, 0, 0, 0};
         for (int k = 0; k < (two ? 2 : 1); k++) {
-            uint64_t part[2] = {0, 0};
+            uint64_t part[kTotals] = {0, 0, 0, 0};
             hip_check(hipMemcpy(part, ds.ws[k].ray_total, sizeof(part), hipMemcpyDeviceToHost), "hipMemcpy D2H");
-            totals[0] += part[0];
-            totals[1] += part[1];
+            for (int c = 0; c < kTotals; c++) totals[c] += part[c];
         }
         stats->rays = task->trace_depth ? totals[0] : 0;
         stats->paths = paths;
         stats->render_ms = ms;
         stats->bvh_bytes = scene->bvh_bytes;
         stats->searches = totals[1];
+        stats->node_visits = totals[2];
+        stats->triangle_tests = totals[3];
         stats->search_kernel_ms = 0.0;
         stats->search_kernel_launches = 0;
         for (size_t i = 0; i + 1 < seg_events.size(); i += 2) {

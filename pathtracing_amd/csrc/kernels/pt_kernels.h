@@ -43,7 +43,9 @@ struct Workspace {
     uint64_t capacity_paths = 0; // records each queue array holds
     uint64_t contrib_paths = 0;  // paths the contribution buffer holds
     uint32_t result_arrays = 0;  // how many of results[] are allocated
-    uint64_t* ray_total = nullptr; // device-side running sums: [0] traced rays, [1] BVH searches
+    // device-side running sums: [0] traced rays, [1] BVH searches, [2] node records and [3] triangle
+    // records the search kernel fetched (counted only on request)
+    uint64_t* ray_total = nullptr;
     // Trace kernels run a persistent grid of `persistent_blocks` blocks; `spill`
     // holds one column of spill_dwords() dwords per thread of that grid.
     uint32_t* spill = nullptr;
@@ -72,10 +74,11 @@ struct BatchGeometry {
 // ray set aside for the children of the scene's instance run (0: the scene has none).
 // `search_events`: when non-null, a pair of events (start, stop) is created and
 // recorded around every search_kernel launch and appended to the vector.
+// `count_visits`: the search kernel counts the node and triangle records it fetches.
 hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeometry& geo, uint64_t seed,
                         uint64_t sample_first, uint32_t sample_count, uint32_t trace_depth, bool brute,
                         const std::vector<MeshTarget>& targets, uint32_t run_slots, Workspace& ws, hipStream_t stream,
-                        std::vector<hipEvent_t>* search_events);
+                        std::vector<hipEvent_t>* search_events, bool count_visits = false);
 
 // Adds a traced batch's colours, per pixel in sample order, into d_accum
 // (camera-space layout, (x + y*W)*3).

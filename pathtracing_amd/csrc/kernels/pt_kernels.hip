@@ -719,11 +719,14 @@ struct SearchResults {
 // lengths differ by an order of magnitude between neighbouring rays).
 // kOneMesh: the scene has a single mesh, `one`; its node and triangle arrays are then kernel
 // arguments (scalar registers) instead of per-lane state read from the mesh table at every refill.
-template <bool kOneMesh>
+// kCount: node records and triangle records fetched are counted into visit_totals[0] / [1] (the
+// measured side of the kernel's byte count; two more registers, so timed runs use the other variant).
+template <bool kOneMesh, bool kCount = false>
 __global__ void __launch_bounds__(kBlock, PT_SEARCH_OCCUPANCY)
 search_kernel(const DMesh* __restrict__ meshes, DMesh one, const float4* __restrict__ job_a, const float4* __restrict__ job_b,
               const float4* __restrict__ job_c, const uint32_t* __restrict__ job_counts, SearchResults out, uint32_t cap,
-              uint32_t job_cap, uint32_t regions, uint32_t* spill, uint32_t spill_threads) {
+              uint32_t job_cap, uint32_t regions, uint32_t* spill, uint32_t spill_threads,
+              unsigned long long* visit_totals = nullptr) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -744,6 +747,7 @@ search_kernel(const DMesh* __restrict__ meshes, DMesh one, const float4* __restr
     Ray ray;
     float4* res_out = nullptr;
     bool busy = false;
+    uint32_t nodes_fetched = 0u, tris_fetched = 0u;
 
     // Every pass of the loops below retires at least one step of some lane's search, and
     // a search ends: inner children have larger indices than their parents (WideNode),
@@ -808,9 +812,15 @@ search_kernel(const DMesh* __restrict__ meshes, DMesh one, const float4* __restr
                     uint32_t n_leaf = (uint32_t)__popcll(__ballot(busy && !trav_done(ts) && !trav_is_inner(ts)));
                     if (n_leaf != 0u) break;
                 }
-                if (at_inner) trav_inner(ts, ray, st);
+                if (at_inner) {
+                    if (kCount) nodes_fetched++;
+                    trav_inner(ts, ray, st);
+                }
             }
-            if (busy && !trav_done(ts) && !trav_is_inner(ts)) trav_leaf(ts, ray, st);
+            if (busy && !trav_done(ts) && !trav_is_inner(ts)) {
+                if (kCount) tris_fetched += ((uint32_t)(~ts.cur) & 7u) + 1u;
+                trav_leaf(ts, ray, st);
+            }
             uint32_t n_unfinished = (uint32_t)__popcll(__ballot(busy && !trav_done(ts)));
             if (n_unfinished == 0u || (more && n_unfinished + kRefill <= n_busy)) break;
         }
@@ -818,6 +828,17 @@ search_kernel(const DMesh* __restrict__ meshes, DMesh one, const float4* __restr
             *res_out = make_float4(ts.tbest, __uint_as_float(ts.found), __uint_as_float(ts.best_slot),
                                    __uint_as_float(ts.best_orig));
             busy = false;
+        }
+    }
+    if (kCount) {
+        unsigned long long n = nodes_fetched, t = tris_fetched;
+        for (int off = 32; off > 0; off >>= 1) {
+            n += __shfl_down(n, off, 64);
+            t += __shfl_down(t, off, 64);
+        }
+        if (lane == 0u) {
+            atomicAdd(visit_totals, n);
+            atomicAdd(visit_totals + 1, t);
         }
     }
 }
@@ -1104,8 +1125,20 @@ hipError_t make_plan(const DScene& scene, size_t target_count, uint32_t run_slot
     return hipSuccess;
 }
 
-void launch_search(const DScene& scene, const SegmentPlan& pl, hipStream_t stream) {
+void launch_search(const DScene& scene, const SegmentPlan& pl, hipStream_t stream, bool count = false) {
     const Workspace& ws = *pl.ws;
+    if (count) {
+        unsigned long long* visits = pl.totals + 2;
+        if (scene.mesh_count == 1u)
+            search_kernel<true, true><<<ws.persistent_blocks, kBlock, 0, stream>>>(
+                scene.meshes, scene.mesh0, ws.jobs[0], ws.jobs[1], ws.jobs[2], ws.job_counts, pl.sr, pl.cap, pl.sl.job_cap,
+                pl.regions, ws.spill, pl.spill_threads, visits);
+        else
+            search_kernel<false, true><<<ws.persistent_blocks, kBlock, 0, stream>>>(
+                scene.meshes, scene.mesh0, ws.jobs[0], ws.jobs[1], ws.jobs[2], ws.job_counts, pl.sr, pl.cap, pl.sl.job_cap,
+                pl.regions, ws.spill, pl.spill_threads, visits);
+        return;
+    }
     if (scene.mesh_count == 1u)
         search_kernel<true><<<ws.persistent_blocks, kBlock, 0, stream>>>(scene.meshes, scene.mesh0, ws.jobs[0], ws.jobs[1],
                                                                         ws.jobs[2], ws.job_counts, pl.sr, pl.cap, pl.sl.job_cap,
@@ -1121,7 +1154,7 @@ void launch_search(const DScene& scene, const SegmentPlan& pl, hipStream_t strea
 hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeometry& geo, uint64_t seed,
                         uint64_t sample_first, uint32_t sample_count, uint32_t trace_depth, bool brute,
                         const std::vector<MeshTarget>& targets, uint32_t run_slots_cfg, Workspace& ws, hipStream_t stream,
-                        std::vector<hipEvent_t>* search_events) {
+                        std::vector<hipEvent_t>* search_events, bool count_visits) {
     RenderParams p;
     p.scene = scene;
     p.cam = cam;
@@ -1161,7 +1194,7 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
                 search_events->push_back(e1);
                 if ((e = hipEventRecord(e0, stream)) != hipSuccess) return e;
             }
-            launch_search(scene, pl, stream);
+            launch_search(scene, pl, stream, count_visits);
             if (search_events && (e = hipEventRecord(e1, stream)) != hipSuccess) return e;
         }
         // one loop over the root's children where the scene has that shape (not in the linear-scan mode,
