@@ -24,6 +24,9 @@ pub const PT_FLAG_SINGLE_STREAM: u32 = 16;
 pub const PT_FLAG_COUNT_VISITS: u32 = 32;
 pub const PT_STATIC_TRACE_MAX_RAYS: u32 = 16777216;
 
+pub const PT_SHARD_SAMPLES: u32 = 0;
+pub const PT_SHARD_ROWS: u32 = 1;
+
 /// `PtStatus`
 pub type PtStatus = c_int;
 pub const PT_OK: PtStatus = 0;
@@ -288,6 +291,25 @@ extern "C" {
         stream: *mut c_void,
     ) -> PtStatus;
 
+    pub fn pt_shard(
+        task: *const PtRenderTask,
+        opts: *const PtRenderOpts,
+        mode: u32,
+        world: u32,
+        rank: u32,
+        out_task: *mut PtRenderTask,
+        out_opts: *mut PtRenderOpts,
+        out_active: *mut u32,
+    ) -> PtStatus;
+    pub fn pt_render_multi(
+        scenes: *mut *mut PtScene,
+        n_devices: c_int,
+        task: *const PtRenderTask,
+        opts: *const PtRenderOpts,
+        mode: u32,
+        out_rgb: *mut f32,
+        stats: *mut PtRenderStats,
+    ) -> PtStatus;
     pub fn pt_trace_closest(
         scene: *mut PtScene,
         rays: *const PtRay,

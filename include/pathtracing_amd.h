@@ -275,6 +275,33 @@ PtStatus pt_render_accumulate_device(PtScene* scene, const PtRenderTask* task,
 PtStatus pt_resolve_device(const float* d_accum, uint64_t width, uint64_t height,
                            uint64_t total_iterations, float* d_out_rgb, void* stream);
 
+/* ------------------------------------------------- several GPUs, one process */
+
+/* How a render is cut over ranks or devices.  The reference combines workers on the host:
+ * the client sends the same task to every worker and averages the frames
+ * (client/src/worker_pool.rs:221-236, client/src/frame.rs:60-84). */
+typedef enum PtShardMode {
+    PT_SHARD_SAMPLES = 0, /* disjoint sample ranges of every pixel (sums differ from one GPU's in f32 order only) */
+    PT_SHARD_ROWS = 1     /* bands of 8-pixel rows, every sample (bit-identical to one GPU's image)               */
+} PtShardMode;
+
+/* The share of `rank` of `world`: out_task / out_opts are `task` / `opts` (NULL: zeros) with
+ * the iterations and sample_offset of the rank's sample range, or the tile of its row band;
+ * *out_active = 0 when the rank has nothing to render. */
+PtStatus pt_shard(const PtRenderTask* task, const PtRenderOpts* opts, uint32_t mode, uint32_t world, uint32_t rank,
+                  PtRenderTask* out_task, PtRenderOpts* out_opts, uint32_t* out_active);
+
+/* Renderer::render on n_devices GPUs of one node from one process: scenes[i] is the scene
+ * resident on the i-th device (pt_scene_create of the same description on each); every
+ * device renders its share (pt_shard, on a stream and host thread of its own), the
+ * un-normalised sums are added onto the first device -- one grouped RCCL reduce(sum) over
+ * xGMI when the devices are distinct and RCCL can be opened, peer copies and adds
+ * otherwise (and with PATHTRACING_AMD_REDUCE=p2p) -- which resolves the image into out_rgb
+ * (host memory, layout as pt_render).  n_devices = 1 is pt_render.  stats (may be NULL):
+ * rays, paths and searches summed over the devices, render_ms = the whole call. */
+PtStatus pt_render_multi(PtScene** scenes, int n_devices, const PtRenderTask* task, const PtRenderOpts* opts,
+                         uint32_t mode, float* out_rgb, PtRenderStats* stats);
+
 /* ----------------------------------------------------- closest-hit contract */
 
 typedef struct PtHit {

@@ -17,8 +17,8 @@
 // third-party behaviours are "parity unpinned": the rand 0.8 generator (the
 // reference never seeds it, so only the distribution and the per-event draw
 // order are restated; the generator here is this project's own counter-based
-// one), tobj's triangulation order and `image`'s PNG decode (both live in the
-// host loader, not here).
+// one), tobj's triangulation order and `image`'s PNG decode (restated in
+// oracle/loaders.py, which uses oracle_png_unfilter below).
 //
 // Two switchable deviations from a literal restatement, both off by default:
 //   accel = 1   meshes are searched through a BVH instead of the linear scan of
@@ -1320,6 +1320,42 @@ void oracle_frame_image(const float* sum, size_t pixels, uint64_t count, float* 
         }
         if (out_rgba) out_rgba[4 * i + 3] = 255;
     }
+}
+
+// PNG scanline reconstruction (PNG specification, "Filtering": types 0 None, 1 Sub, 2 Up,
+// 3 Average, 4 Paeth) for oracle/loaders.py, which restates the host loaders that feed the
+// path (image.rs:13-19 decodes through the `image` crate).  `filtered` holds `height` rows of
+// 1 + stride bytes (filter type, then the row), `bpp` = bytes per complete pixel (at least 1);
+// `out` receives height * stride bytes.  Returns 0, or 1 on an unknown filter type.
+int oracle_png_unfilter(const uint8_t* filtered, uint32_t height, uint32_t stride, uint32_t bpp, uint8_t* out) {
+    for (uint32_t y = 0; y < height; y++) {
+        const uint8_t* in = filtered + (size_t)y * (stride + 1);
+        const uint8_t type = in[0];
+        in++;
+        uint8_t* row = out + (size_t)y * stride;
+        const uint8_t* up = y ? row - stride : nullptr;
+        for (uint32_t i = 0; i < stride; i++) {
+            const int a = i >= bpp ? row[i - bpp] : 0;
+            const int b = up ? up[i] : 0;
+            const int c = (up && i >= bpp) ? up[i - bpp] : 0;
+            int pred;
+            switch (type) {
+            case 0: pred = 0; break;
+            case 1: pred = a; break;
+            case 2: pred = b; break;
+            case 3: pred = (a + b) >> 1; break;
+            case 4: {
+                const int p = a + b - c;
+                const int pa = p > a ? p - a : a - p, pb = p > b ? p - b : b - p, pc = p > c ? p - c : c - p;
+                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                break;
+            }
+            default: return 1;
+            }
+            row[i] = (uint8_t)(in[i] + pred);
+        }
+    }
+    return 0;
 }
 
 } // extern "C"

@@ -5,6 +5,7 @@ compute path is the HIP library and nothing else.
 """
 from .api import Camera, Config, RenderOpts, RenderTask
 from .frame import Frame
+from .multi import render_multi
 from .renderer import HIT_DTYPE, HipRenderer, Renderer, generate_rays
 from .scene import Scene
 from .worker import RenderedImage, Worker
@@ -21,5 +22,6 @@ __all__ = [
     "Worker",
     "RenderedImage",
     "generate_rays",
+    "render_multi",
     "HIT_DTYPE",
 ]

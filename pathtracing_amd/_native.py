@@ -27,6 +27,7 @@ NODE_COLLECTION, NODE_TRANSFORM, NODE_MESH, NODE_SPHERE, NODE_PLANE, NODE_KD_TRE
 MATERIAL_BASE, MATERIAL_PBR = 0, 1
 UV_CLAMP, UV_REPEAT = 0, 1
 BOKEH_POINT, BOKEH_CIRCLE, BOKEH_SQUARE = 0, 1, 2
+SHARD_SAMPLES, SHARD_ROWS = 0, 1
 
 STATUS_NAMES = {
     0: "PT_OK",
@@ -215,6 +216,10 @@ SYMBOLS = {
         [_VOIDP, C.POINTER(PtRenderTask), C.POINTER(PtRenderOpts), _VOIDP, _VOIDP, C.POINTER(PtRenderStats)],
     ),
     "pt_resolve_device": (C.c_int, [_VOIDP, C.c_uint64, C.c_uint64, C.c_uint64, _VOIDP, _VOIDP]),
+    "pt_shard": (C.c_int, [C.POINTER(PtRenderTask), C.POINTER(PtRenderOpts), C.c_uint32, C.c_uint32, C.c_uint32,
+                          C.POINTER(PtRenderTask), C.POINTER(PtRenderOpts), C.POINTER(C.c_uint32)]),
+    "pt_render_multi": (C.c_int, [C.POINTER(_VOIDP), C.c_int, C.POINTER(PtRenderTask), C.POINTER(PtRenderOpts), C.c_uint32,
+                                 _VOIDP, C.POINTER(PtRenderStats)]),
     "pt_trace_closest": (C.c_int, [_VOIDP, _VOIDP, C.c_size_t, C.c_uint32, _VOIDP]),
     "pt_trace_closest_device_static": (C.c_int, [_VOIDP, _VOIDP, C.c_size_t, C.c_uint32, _VOIDP, _VOIDP]),
     "pt_generate_rays": (C.c_int, [C.POINTER(PtCamera), C.c_uint64, _VOIDP, _VOIDP, C.c_size_t, C.c_int, _VOIDP]),

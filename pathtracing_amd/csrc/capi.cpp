@@ -1,6 +1,8 @@
 // C ABI of the library (include/pathtracing_amd.h): scene upload, render,
 // closest-hit queries, host loaders.  Nothing here may throw across the boundary.
+#include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h> // types only: the library is opened at the first multi-GPU reduce (see Rccl below)
 
 #include <algorithm>
 #include <chrono>
@@ -12,6 +14,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pathtracing_amd.h"
@@ -76,16 +79,19 @@ struct DeviceGuard {
 // `mu` serialises the host side (sizing and enqueueing), so calls may come from
 // several threads.  A DeviceState lives until the process ends
 // (pt_device_release_workspace frees its device memory earlier).
+constexpr int kMaxInFlight = 4; // batches of one render traced at the same time, each in a workspace of its own
 struct DeviceState {
     int device = 0;
     std::mutex mu;
-    ptk::Workspace ws[2];
-    hipEvent_t last_use[2] = {nullptr, nullptr};
-    bool used[2] = {false, false};
-    hipStream_t side = nullptr;      // every other batch of a render that keeps two batches in flight
-    hipEvent_t fork = nullptr;       // the caller's stream at the start of such a render
-    hipEvent_t side_done = nullptr;  // a batch traced on `side`
-    hipEvent_t accumulated = nullptr; // ... and added to the image on the caller's stream
+    ptk::Workspace ws[kMaxInFlight];
+    hipEvent_t last_use[kMaxInFlight] = {};
+    bool used[kMaxInFlight] = {};
+    // with batches in flight workspace k is traced on side[k], a stream of the library's own; the caller's stream
+    // then only adds the batches' colours to the image, in batch order
+    hipStream_t side[kMaxInFlight] = {};
+    hipEvent_t fork = nullptr;                   // the caller's stream at the start of a render with batches in flight
+    hipEvent_t side_done[kMaxInFlight] = {};     // a batch traced on side[k]
+    hipEvent_t accumulated[kMaxInFlight] = {};   // ... and added to the image on the caller's stream
 };
 
 namespace {
@@ -698,10 +704,11 @@ struct PtFrame {
 
 namespace {
 
-// PATHTRACING_AMD_STREAMS=1: renders never keep two batches in flight.
-bool two_streams_allowed() {
+// How many batches of a render may be traced at the same time: PATHTRACING_AMD_STREAMS (1..4), default 2.
+int batches_in_flight_allowed() {
     const char* v = getenv("PATHTRACING_AMD_STREAMS");
-    return !(v && atoi(v) == 1);
+    int n = v ? atoi(v) : 2;
+    return std::max(1, std::min(n, kMaxInFlight));
 }
 
 void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderOpts* opts_in, float* d_accum,
@@ -727,15 +734,17 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
     const bool profile = stats && (o.flags & PT_FLAG_PROFILE) != 0;
     const bool count_visits = stats && (o.flags & PT_FLAG_COUNT_VISITS) != 0;
     // Path slots per batch.  Bigger batches are faster (fewer launches whose last waves run alone, more
-    // samples of a pixel block next to each other); a slot costs about 210 bytes of queues, nine times
+    // samples of a pixel block next to each other), and two batches in flight are faster than one of
+    // twice the size (what one batch's launches leave idle, the other's fill: 96 ms against 107 per
+    // 1080p x 64 spp frame of the 871k-triangle scene).  A slot costs about 210 bytes of queues, nine times
     // the job records on top for scenes with an instance run.  The default is halved until it fits.
-    uint64_t budget = o.paths_per_batch ? o.paths_per_batch : ((scene->run_slots ? 32ull : 128ull) << 20);
+    uint64_t budget = o.paths_per_batch ? o.paths_per_batch : ((scene->run_slots ? 16ull : 64ull) << 20);
     if (budget < 64) budget = 64;
     const uint32_t nbx = (w + 7) / 8;
     const uint64_t slots_per_block_row = (uint64_t)nbx * 64;
     const uint32_t total_block_rows = (h + 7) / 8;
     uint32_t band_block_rows = 0, samples_per_batch = 0;
-    bool two = false; // two batches in flight: the second workspace on the side stream
+    int flight = 1; // batches in flight: batch i is traced in workspace i mod flight (flight > 1: on side stream i mod flight)
     ensure_trace_state(ds, 0);
     const uint32_t waves = ds.ws[0].persistent_blocks * (ptk::kTraceBlock / 64);
     for (;;) {
@@ -747,25 +756,22 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
         while ((uint64_t)samples_per_batch * band_slots > 0xFFFFFFFFull && samples_per_batch > 1) samples_per_batch /= 2;
         const uint64_t n_batches = (uint64_t)((total_block_rows + band_block_rows - 1) / band_block_rows) *
                                    ((task->iterations + samples_per_batch - 1) / samples_per_batch);
-        two = n_batches >= 2 && !profile && !(o.flags & PT_FLAG_SINGLE_STREAM) && two_streams_allowed();
+        flight = (profile || count_visits || (o.flags & PT_FLAG_SINGLE_STREAM)) ? 1 : batches_in_flight_allowed();
+        flight = (int)std::min<uint64_t>((uint64_t)flight, std::max<uint64_t>(n_batches, 1));
         const uint64_t records = (uint64_t)ptk::queue_region_capacity(nbx, band_block_rows, samples_per_batch, waves) * waves;
         const uint64_t paths = band_slots * samples_per_batch;
         bool ok = ensure_workspace(ds, 0, records, paths, scene->result_arrays(), scene->run_slots);
-        if (ok && two) {
-            ok = ensure_workspace(ds, 1, records, paths, scene->result_arrays(), scene->run_slots);
-            if (!ok) { // one workspace fits, two do not: render with one
-                two = false;
-                ok = true;
-            }
-        }
+        for (int k = 1; ok && k < flight; k++)
+            if (!ensure_workspace(ds, k, records, paths, scene->result_arrays(), scene->run_slots)) flight = k; // what fits
         if (ok) break;
         if (o.paths_per_batch || budget <= (1ull << 20))
             throw Error(PT_ERR_DEVICE, "out of device memory for the render's queues (paths_per_batch " + std::to_string(budget) + ")");
         budget /= 2;
     }
-    if (two) {
-        if (!ds.side) hip_check(hipStreamCreateWithFlags(&ds.side, hipStreamNonBlocking), "hipStreamCreate");
-        for (hipEvent_t* e : {&ds.fork, &ds.side_done, &ds.accumulated})
+    const bool piped = flight > 1;
+    for (int k = 0; piped && k < flight; k++) {
+        if (!ds.side[k]) hip_check(hipStreamCreateWithFlags(&ds.side[k], hipStreamNonBlocking), "hipStreamCreate");
+        for (hipEvent_t* e : {&ds.fork, &ds.side_done[k], &ds.accumulated[k]})
             if (!*e) hip_check(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate");
     }
 
@@ -787,11 +793,11 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
         }
     } drain;
     // whatever used the workspaces last (another scene, another stream) comes first
-    stream_acquire(ds, 0, stream);
-    if (two) {
-        hip_check(hipEventRecord(ds.fork, stream), "hipEventRecord");
-        hip_check(hipStreamWaitEvent(ds.side, ds.fork, 0), "hipStreamWaitEvent");
-        stream_acquire(ds, 1, ds.side);
+    if (!piped) stream_acquire(ds, 0, stream);
+    if (piped) hip_check(hipEventRecord(ds.fork, stream), "hipEventRecord");
+    for (int k = 0; piped && k < flight; k++) {
+        hip_check(hipStreamWaitEvent(ds.side[k], ds.fork, 0), "hipStreamWaitEvent");
+        stream_acquire(ds, k, ds.side[k]);
     }
     if (stats) {
         hipEvent_t e = nullptr;
@@ -799,12 +805,12 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
         events.push_back(e);
         hip_check(hipEventCreate(&e), "hipEventCreate");
         events.push_back(e);
-        hip_check(hipMemsetAsync(ds.ws[0].ray_total, 0, kTotals * sizeof(uint64_t), stream), "hipMemsetAsync");
-        if (two) hip_check(hipMemsetAsync(ds.ws[1].ray_total, 0, kTotals * sizeof(uint64_t), ds.side), "hipMemsetAsync");
+        for (int k = 0; k < flight; k++)
+            hip_check(hipMemsetAsync(ds.ws[k].ray_total, 0, kTotals * sizeof(uint64_t), piped ? ds.side[k] : stream), "hipMemsetAsync");
         hip_check(hipEventRecord(events[0], stream), "hipEventRecord");
     }
     uint64_t paths = 0, batch_index = 0;
-    bool side_holds_contrib = false; // workspace 1's colours are still to be read by an accumulate on `stream`
+    bool holds_contrib[kMaxInFlight] = {}; // workspace k's colours are still to be read by an accumulate on `stream`
     for (uint32_t br = 0; br < total_block_rows; br += band_block_rows) {
         ptk::BatchGeometry g;
         g.x0 = x0;
@@ -816,29 +822,28 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
         g.npp = g.nbx * g.nby * 64;
         for (uint64_t s = 0; s < task->iterations; s += samples_per_batch, batch_index++) {
             const uint32_t cnt = (uint32_t)std::min<uint64_t>(samples_per_batch, task->iterations - s);
-            const int k = two ? (int)(batch_index & 1u) : 0;
-            hipStream_t st = k ? ds.side : stream;
-            // workspace 1 is free again once the colours of its previous batch have been added to the image
-            if (k == 1 && side_holds_contrib) hip_check(hipStreamWaitEvent(ds.side, ds.accumulated, 0), "hipStreamWaitEvent");
+            const int k = (int)(batch_index % (uint64_t)flight);
+            hipStream_t st = piped ? ds.side[k] : stream;
+            // a workspace is free again once the colours of its previous batch have been added to the image
+            if (piped && holds_contrib[k]) hip_check(hipStreamWaitEvent(ds.side[k], ds.accumulated[k], 0), "hipStreamWaitEvent");
             hip_check(ptk::render_batch(scene->d, cam, g, o.seed, o.sample_offset + s, cnt, (uint32_t)task->trace_depth,
                                         brute, scene->targets, scene->run_slots, ds.ws[k], st,
                                         profile ? &seg_events : nullptr, count_visits),
                       "render_batch");
-            if (k == 1) {
-                hip_check(hipEventRecord(ds.side_done, ds.side), "hipEventRecord");
-                hip_check(hipStreamWaitEvent(stream, ds.side_done, 0), "hipStreamWaitEvent");
+            if (piped) {
+                hip_check(hipEventRecord(ds.side_done[k], ds.side[k]), "hipEventRecord");
+                hip_check(hipStreamWaitEvent(stream, ds.side_done[k], 0), "hipStreamWaitEvent");
             }
             // the per-pixel sums stay in sample order: every batch is added on the caller's stream, in batch order
             hip_check(ptk::accumulate_batch(g, cam.width, cnt, ds.ws[k], d_accum, stream), "accumulate_batch");
-            if (k == 1) {
-                hip_check(hipEventRecord(ds.accumulated, stream), "hipEventRecord");
-                side_holds_contrib = true;
+            if (piped) {
+                hip_check(hipEventRecord(ds.accumulated[k], stream), "hipEventRecord");
+                holds_contrib[k] = true;
             }
             paths += (uint64_t)cnt * g.w * g.h;
         }
     }
-    stream_release(ds, 0, stream);
-    if (two) stream_release(ds, 1, stream); // `stream` has waited for everything queued on the side stream
+    for (int k = 0; k < flight; k++) stream_release(ds, k, stream); // `stream` has waited for everything queued on the side streams
     drain.armed = false;
     if (stats) {
         hip_check(hipEventRecord(events[1], stream), "hipEventRecord");
@@ -846,7 +851,7 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
         float ms = 0.0f;
         hip_check(hipEventElapsedTime(&ms, events[0], events[1]), "hipEventElapsedTime");
         uint64_t totals[kTotals] = {0, 0, 0, 0};
-        for (int k = 0; k < (two ? 2 : 1); k++) {
+        for (int k = 0; k < flight; k++) {
             uint64_t part[kTotals] = {0, 0, 0, 0};
             hip_check(hipMemcpy(part, ds.ws[k].ray_total, sizeof(part), hipMemcpyDeviceToHost), "hipMemcpy D2H");
             for (int c = 0; c < kTotals; c++) totals[c] += part[c];
@@ -866,6 +871,237 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
             stats->search_kernel_ms += seg;
             stats->search_kernel_launches++;
         }
+    }
+}
+
+} // namespace
+
+
+// ------------------------------------------------------------ several GPUs, one process
+namespace {
+
+// The share of `rank` of `world` (the split pathtracing_amd/distributed.py makes for the one-process-per-GPU path).
+// Sample ranges are contiguous and disjoint, the first `iterations % world` ranks get one sample more; row bands are
+// whole 8-pixel block rows except the last.  False: nothing to render.
+bool shard(const PtRenderTask& task, const PtRenderOpts& opts, uint32_t mode, uint32_t world, uint32_t rank,
+           PtRenderTask* out_task, PtRenderOpts* out_opts) {
+    if (world == 0 || rank >= world) throw Error(PT_ERR_INVALID_ARGUMENT, "bad rank / world size");
+    *out_task = task;
+    *out_opts = opts;
+    if (mode == PT_SHARD_SAMPLES) {
+        const uint64_t base = task.iterations / world, extra = task.iterations % world;
+        const uint64_t count = base + (rank < extra ? 1 : 0);
+        const uint64_t first = (uint64_t)rank * base + std::min<uint64_t>(rank, extra);
+        out_task->iterations = count;
+        out_opts->sample_offset = opts.sample_offset + first;
+        return count != 0;
+    }
+    if (mode == PT_SHARD_ROWS) {
+        const uint64_t height = task.camera.resolution_y, width = task.camera.resolution_x;
+        const uint64_t blocks = (height + 7) / 8, base = blocks / world, extra = blocks % world;
+        const uint64_t nblk = base + (rank < extra ? 1 : 0);
+        const uint64_t first_blk = (uint64_t)rank * base + std::min<uint64_t>(rank, extra);
+        const uint64_t y0 = first_blk * 8;
+        const uint64_t end = std::min<uint64_t>(height, (first_blk + nblk) * 8);
+        const uint64_t rows = end > y0 ? end - y0 : 0;
+        out_opts->tile_x0 = 0;
+        out_opts->tile_y0 = (uint32_t)y0;
+        out_opts->tile_w = (uint32_t)width;
+        out_opts->tile_h = (uint32_t)rows;
+        return rows != 0;
+    }
+    throw Error(PT_ERR_INVALID_ARGUMENT, "unknown sharding mode");
+}
+
+// RCCL, opened on first use by its soname: a process that has loaded another copy already (PyTorch wheels bundle
+// one under the same soname) keeps using that copy, and a single-GPU process never loads it.
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclCommInitAll) comm_init_all = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclReduce) reduce = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    bool ok = false;
+    Rccl() {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (handle) break;
+        }
+        if (!handle) return;
+        comm_init_all = reinterpret_cast<decltype(comm_init_all)>(dlsym(handle, "ncclCommInitAll"));
+        comm_destroy = reinterpret_cast<decltype(comm_destroy)>(dlsym(handle, "ncclCommDestroy"));
+        reduce = reinterpret_cast<decltype(reduce)>(dlsym(handle, "ncclReduce"));
+        group_start = reinterpret_cast<decltype(group_start)>(dlsym(handle, "ncclGroupStart"));
+        group_end = reinterpret_cast<decltype(group_end)>(dlsym(handle, "ncclGroupEnd"));
+        error_string = reinterpret_cast<decltype(error_string)>(dlsym(handle, "ncclGetErrorString"));
+        ok = comm_init_all && comm_destroy && reduce && group_start && group_end && error_string;
+    }
+    void check(ncclResult_t r, const char* what) const {
+        if (r != ncclSuccess) throw Error(PT_ERR_DEVICE, std::string(what) + ": " + error_string(r));
+    }
+};
+Rccl& rccl() {
+    static Rccl* r = new Rccl(); // never unloaded
+    return *r;
+}
+
+// One communicator set per device list, kept for the life of the process (setting one up takes seconds).
+std::vector<ncclComm_t>& communicators(const std::vector<int>& devices) {
+    static std::mutex mu;
+    static std::map<std::vector<int>, std::vector<ncclComm_t>>* cache = new std::map<std::vector<int>, std::vector<ncclComm_t>>();
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache->find(devices);
+    if (it != cache->end()) return it->second;
+    std::vector<ncclComm_t> comms(devices.size());
+    rccl().check(rccl().comm_init_all(comms.data(), (int)devices.size(), devices.data()), "ncclCommInitAll");
+    return (*cache)[devices] = comms;
+}
+
+// Per-device resources of one pt_render_multi call.
+struct Lane {
+    PtScene* scene = nullptr;
+    hipStream_t stream = nullptr;
+    float* accum = nullptr;
+    PtRenderTask task{};
+    PtRenderOpts opts{};
+    bool active = false;
+    PtRenderStats stats{};
+    PtStatus status = PT_OK;
+    std::string message;
+};
+
+void render_multi(PtScene** scenes, int n, const PtRenderTask* task, const PtRenderOpts* opts_in, uint32_t mode,
+                  float* out_rgb, PtRenderStats* stats) {
+    if (!scenes || !task || !out_rgb) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+    if (n < 1 || n > 64) throw Error(PT_ERR_INVALID_ARGUMENT, "pt_render_multi takes 1 to 64 scenes");
+    for (int i = 0; i < n; i++)
+        if (!scenes[i]) throw Error(PT_ERR_INVALID_ARGUMENT, "null scene");
+    (void)make_camera(task->camera);
+    PtRenderOpts base;
+    memset(&base, 0, sizeof(base));
+    if (opts_in) base = *opts_in;
+    const size_t floats = (size_t)task->camera.resolution_x * task->camera.resolution_y * 3;
+    const size_t bytes = floats * sizeof(float);
+    const auto t_start = std::chrono::steady_clock::now();
+    std::vector<Lane> lanes((size_t)n);
+    float *staging = nullptr, *resolved = nullptr;
+    struct Cleanup {
+        std::vector<Lane>& lanes;
+        float*& staging;
+        float*& resolved;
+        ~Cleanup() {
+            for (Lane& l : lanes) {
+                if (!l.scene) continue;
+                (void)hipSetDevice(l.scene->device);
+                if (l.stream) {
+                    (void)hipStreamSynchronize(l.stream);
+                    (void)hipStreamDestroy(l.stream);
+                }
+                if (l.accum) (void)hipFree(l.accum);
+            }
+            if (!lanes.empty() && lanes[0].scene) (void)hipSetDevice(lanes[0].scene->device);
+            if (staging) (void)hipFree(staging);
+            if (resolved) (void)hipFree(resolved);
+        }
+    } cleanup{lanes, staging, resolved};
+    int prev_device = 0;
+    hip_check(hipGetDevice(&prev_device), "hipGetDevice");
+    struct Restore {
+        int dev;
+        ~Restore() { (void)hipSetDevice(dev); }
+    } restore{prev_device};
+
+    for (int i = 0; i < n; i++) {
+        Lane& l = lanes[(size_t)i];
+        l.scene = scenes[i];
+        l.active = shard(*task, base, mode, (uint32_t)n, (uint32_t)i, &l.task, &l.opts);
+        hip_check(hipSetDevice(l.scene->device), "hipSetDevice");
+        hip_check(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking), "hipStreamCreate");
+        hip_check(hipMalloc(reinterpret_cast<void**>(&l.accum), bytes ? bytes : 16), "hipMalloc accumulation buffer");
+        hip_check(hipMemsetAsync(l.accum, 0, bytes, l.stream), "hipMemsetAsync");
+    }
+    // every device renders its share; one host thread per device keeps them all busy
+    std::vector<std::thread> threads;
+    for (int i = 0; i < n; i++) {
+        Lane* l = &lanes[(size_t)i];
+        if (!l->active) continue;
+        threads.emplace_back([l] {
+            l->status = guarded([&] {
+                hip_check(hipSetDevice(l->scene->device), "hipSetDevice");
+                render_accumulate(l->scene, &l->task, &l->opts, l->accum, l->stream, &l->stats);
+            });
+            if (l->status != PT_OK) l->message = pt::last_error_string();
+        });
+    }
+    for (std::thread& t : threads) t.join();
+    for (const Lane& l : lanes)
+        if (l.status != PT_OK) throw Error(l.status, l.message);
+    for (Lane& l : lanes) { // lanes without a share have only their memset queued
+        hip_check(hipSetDevice(l.scene->device), "hipSetDevice");
+        hip_check(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
+    }
+
+    // the sum of the un-normalised buffers onto the first device (client/src/frame.rs:60-71 does it on the host)
+    Lane& root = lanes[0];
+    if (n > 1) {
+        std::vector<int> devices;
+        bool distinct = true;
+        for (const Lane& l : lanes) {
+            for (int d : devices) distinct = distinct && d != l.scene->device;
+            devices.push_back(l.scene->device);
+        }
+        const char* how = getenv("PATHTRACING_AMD_REDUCE");
+        const bool want_p2p = how && strcmp(how, "p2p") == 0;
+        if (distinct && !want_p2p && rccl().ok) {
+            // RCCL over xGMI: one grouped ncclReduce(sum) with root 0, each rank on its own stream
+            std::vector<ncclComm_t>& comms = communicators(devices);
+            rccl().check(rccl().group_start(), "ncclGroupStart");
+            for (int i = 0; i < n; i++) {
+                hip_check(hipSetDevice(lanes[(size_t)i].scene->device), "hipSetDevice");
+                rccl().check(rccl().reduce(lanes[(size_t)i].accum, root.accum, floats, ncclFloat, ncclSum, 0, comms[(size_t)i],
+                                           lanes[(size_t)i].stream),
+                             "ncclReduce");
+            }
+            rccl().check(rccl().group_end(), "ncclGroupEnd");
+            for (Lane& l : lanes) {
+                hip_check(hipSetDevice(l.scene->device), "hipSetDevice");
+                hip_check(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
+            }
+        } else {
+            // peer copies: every other buffer is copied to the first device and added there, in device order
+            // (also the route for several scenes on one device, which RCCL does not take)
+            hip_check(hipSetDevice(root.scene->device), "hipSetDevice");
+            hip_check(hipMalloc(reinterpret_cast<void**>(&staging), bytes ? bytes : 16), "hipMalloc staging");
+            for (int i = 1; i < n; i++) {
+                hip_check(hipMemcpyPeerAsync(staging, root.scene->device, lanes[(size_t)i].accum, lanes[(size_t)i].scene->device,
+                                             bytes, root.stream),
+                          "hipMemcpyPeerAsync");
+                hip_check(ptk::frame_add(root.accum, staging, floats, root.stream), "frame_add");
+            }
+        }
+    }
+    hip_check(hipSetDevice(root.scene->device), "hipSetDevice");
+    hip_check(hipMalloc(reinterpret_cast<void**>(&resolved), bytes ? bytes : 16), "hipMalloc image");
+    // get_image: work_group.rs:67-69 scale, cpu_renderer/mod.rs:143-175 flip
+    const float scale = 1.0f / (float)task->iterations;
+    hip_check(ptk::resolve_image(root.accum, (uint32_t)task->camera.resolution_x, (uint32_t)task->camera.resolution_y, scale,
+                                 resolved, root.stream),
+              "resolve_image");
+    hip_check(hipMemcpyAsync(out_rgb, resolved, bytes, hipMemcpyDeviceToHost, root.stream), "hipMemcpy D2H");
+    hip_check(hipStreamSynchronize(root.stream), "hipStreamSynchronize");
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        for (const Lane& l : lanes) {
+            if (!l.active) continue;
+            stats->rays += l.stats.rays;
+            stats->paths += l.stats.paths;
+            stats->searches += l.stats.searches;
+            stats->bvh_bytes = l.stats.bvh_bytes;
+        }
+        // the whole call on the host's clock: renders side by side, the reduce, the resolve and the copy back
+        stats->render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     }
 }
 
@@ -1059,7 +1295,7 @@ PtStatus pt_device_release_workspace(int device) {
         DeviceGuard guard(device);
         DeviceState& ds = device_state(device);
         std::lock_guard<std::mutex> lock(ds.mu);
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < kMaxInFlight; k++) {
             wait_idle(ds, k);
             free_workspace(ds.ws[k]);
             free_trace_state(ds.ws[k]);
@@ -1107,6 +1343,22 @@ PtStatus pt_render(PtScene* scene, const PtRenderTask* task, const PtRenderOpts*
                   "resolve_image");
         hip_check(hipMemcpy(out_rgb, out.p, floats * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy D2H");
     });
+}
+
+PtStatus pt_shard(const PtRenderTask* task, const PtRenderOpts* opts, uint32_t mode, uint32_t world, uint32_t rank,
+                  PtRenderTask* out_task, PtRenderOpts* out_opts, uint32_t* out_active) {
+    return guarded([&] {
+        if (!task || !out_task || !out_opts || !out_active) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        PtRenderOpts base;
+        memset(&base, 0, sizeof(base));
+        if (opts) base = *opts;
+        *out_active = shard(*task, base, mode, world, rank, out_task, out_opts) ? 1u : 0u;
+    });
+}
+
+PtStatus pt_render_multi(PtScene** scenes, int n_devices, const PtRenderTask* task, const PtRenderOpts* opts,
+                         uint32_t mode, float* out_rgb, PtRenderStats* stats) {
+    return guarded([&] { render_multi(scenes, n_devices, task, opts, mode, out_rgb, stats); });
 }
 
 PtStatus pt_frame_create(uint32_t width, uint32_t height, int device, PtFrame** out_frame) {

@@ -586,8 +586,11 @@ bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList sl, u
 // chunk's records ahead, as bounce_kernel does, costs more in spills than it hides here.  Scenes with an instance run keep the two kernels: the
 // walk reads the segment's job list while the bounce overwrites it with the next segment's.
 // kFull: as in walk_kernel.
+#ifndef PT_WALK_BOUNCE_OCCUPANCY
+#define PT_WALK_BOUNCE_OCCUPANCY 3
+#endif
 template <bool kFull = false>
-__global__ void __launch_bounds__(kBlock, 3)
+__global__ void __launch_bounds__(kBlock, PT_WALK_BOUNCE_OCCUPANCY)
 walk_bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList sl, uint32_t cap, uint32_t regions,
                    float* contrib, unsigned long long* ray_total, uint32_t* spill, uint32_t spill_threads,
                    PtHit* full_hits = nullptr) {
