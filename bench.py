@@ -33,7 +33,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
-VALU_PEAK_PER_S = 256 * 4 * 2.4e9 / 2  # wave64 vector instructions per second: 1024 SIMD-32 units, 2 cycles each, 2.4 GHz
+# wave64 vector instructions per second: 1024 SIMDs, four cycles each (SQ_ACTIVE_INST_VALU, which counts quad-cycles,
+# equals SQ_INSTS_VALU for these kernels: profiles/r2_diag_counters.txt), 2.4 GHz
+VALU_PEAK_PER_S = 256 * 4 * 2.4e9 / 4
 DEPTH = 8
 CONFIGS = {
     "c3": {"width": 1920, "height": 1080, "spp": 64, "mode": "samples", "scaling": "weak"},
@@ -147,6 +149,9 @@ def search_kernel_record(P, renderer, task, opts_base, accum_ptr, stream):
         "searches_per_ray": cnt.searches / cnt.rays, "search_kernel_share_of_render": prof.search_kernel_ms / prof.render_ms,
         "searches_per_s_in_kernel": cnt.searches / (prof.search_kernel_ms * 1e-3),
         "bvh_bytes": int(cnt.bvh_bytes), "render_ms_profiled": prof.render_ms,
+        # of a wave's 64 lanes, how many are at work in a node step / a triangle round (each lane runs its own search)
+        "lanes_per_node_step": cnt.node_visits / max(cnt.wave_node_steps, 1),
+        "lanes_per_triangle_round": cnt.triangle_tests / max(cnt.wave_leaf_rounds, 1),
     }
 
 

@@ -228,6 +228,9 @@ pub struct PtRenderStats {
     pub search_kernel_launches: u64,
     pub node_visits: u64,
     pub triangle_tests: u64,
+    pub wave_node_steps: u64,
+    pub wave_leaf_steps: u64,
+    pub wave_leaf_rounds: u64,
 }
 
 #[repr(C)]

@@ -249,6 +249,11 @@ typedef struct PtRenderStats {
     uint64_t search_kernel_launches; /* PT_FLAG_PROFILE: how many launches that sum covers    */
     uint64_t node_visits;    /* PT_FLAG_COUNT_VISITS: 64-byte node records the searches fetched */
     uint64_t triangle_tests; /* PT_FLAG_COUNT_VISITS: 48-byte triangle records they tested      */
+    /* PT_FLAG_COUNT_VISITS, per wave of 64 lanes: node steps taken (each serves the lanes that are at
+     * an inner node), leaf steps taken, and the triangle rounds inside them (a leaf step lasts as
+     * many rounds as its fullest leaf has triangles): node_visits / (64 * wave_node_steps) is the
+     * share of lanes at work in a node step */
+    uint64_t wave_node_steps, wave_leaf_steps, wave_leaf_rounds;
 } PtRenderStats;
 
 /* Renderer::render (renderer/mod.rs:12) -> Rgb32FImage: fills out_rgb

@@ -184,6 +184,9 @@ class PtRenderStats(C.Structure):
         ("search_kernel_launches", C.c_uint64),
         ("node_visits", C.c_uint64),
         ("triangle_tests", C.c_uint64),
+        ("wave_node_steps", C.c_uint64),
+        ("wave_leaf_steps", C.c_uint64),
+        ("wave_leaf_rounds", C.c_uint64),
     ]
 
 

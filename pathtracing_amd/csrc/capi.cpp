@@ -96,7 +96,7 @@ struct DeviceState {
 
 namespace {
 
-constexpr int kTotals = 4; // Workspace::ray_total: rays, searches, node records fetched, triangle records fetched
+constexpr int kTotals = 8; // Workspace::ray_total: rays, searches, node and triangle records fetched, wave-level step counts
 
 DeviceState& device_state(int device) {
     static std::mutex registry_mu;
@@ -850,9 +850,9 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
         hip_check(hipEventSynchronize(events[1]), "hipEventSynchronize");
         float ms = 0.0f;
         hip_check(hipEventElapsedTime(&ms, events[0], events[1]), "hipEventElapsedTime");
-        uint64_t totals[kTotals] = {0, 0, 0, 0};
+        uint64_t totals[kTotals] = {};
         for (int k = 0; k < flight; k++) {
-            uint64_t part[kTotals] = {0, 0, 0, 0};
+            uint64_t part[kTotals] = {};
             hip_check(hipMemcpy(part, ds.ws[k].ray_total, sizeof(part), hipMemcpyDeviceToHost), "hipMemcpy D2H");
             for (int c = 0; c < kTotals; c++) totals[c] += part[c];
         }
@@ -863,6 +863,9 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
         stats->searches = totals[1];
         stats->node_visits = totals[2];
         stats->triangle_tests = totals[3];
+        stats->wave_node_steps = totals[4];
+        stats->wave_leaf_steps = totals[5];
+        stats->wave_leaf_rounds = totals[6];
         stats->search_kernel_ms = 0.0;
         stats->search_kernel_launches = 0;
         for (size_t i = 0; i + 1 < seg_events.size(); i += 2) {

@@ -751,6 +751,7 @@ search_kernel(const DMesh* __restrict__ meshes, DMesh one, const float4* __restr
     float4* res_out = nullptr;
     bool busy = false;
     uint32_t nodes_fetched = 0u, tris_fetched = 0u;
+    uint32_t inner_steps = 0u, leaf_steps = 0u, leaf_rounds = 0u; // wave-level: steps taken, triangle rounds inside leaf steps
 
     // Every pass of the loops below retires at least one step of some lane's search, and
     // a search ends: inner children have larger indices than their parents (WideNode),
@@ -815,12 +816,21 @@ search_kernel(const DMesh* __restrict__ meshes, DMesh one, const float4* __restr
                     uint32_t n_leaf = (uint32_t)__popcll(__ballot(busy && !trav_done(ts) && !trav_is_inner(ts)));
                     if (n_leaf != 0u) break;
                 }
+                if (kCount) inner_steps++;
                 if (at_inner) {
                     if (kCount) nodes_fetched++;
                     trav_inner(ts, ray, st);
                 }
             }
-            if (busy && !trav_done(ts) && !trav_is_inner(ts)) {
+            const bool at_leaf = busy && !trav_done(ts) && !trav_is_inner(ts);
+            if (kCount) {
+                // a leaf step lasts as many triangle rounds as its fullest leaf has triangles
+                uint32_t mine = at_leaf ? ((uint32_t)(~ts.cur) & 7u) + 1u : 0u, rounds = 0u;
+                for (uint32_t c = 1; c <= 4u; c++) rounds += __ballot(mine >= c) != 0ull ? 1u : 0u;
+                leaf_steps += rounds ? 1u : 0u;
+                leaf_rounds += rounds;
+            }
+            if (at_leaf) {
                 if (kCount) tris_fetched += ((uint32_t)(~ts.cur) & 7u) + 1u;
                 trav_leaf(ts, ray, st);
             }
@@ -842,6 +852,9 @@ search_kernel(const DMesh* __restrict__ meshes, DMesh one, const float4* __restr
         if (lane == 0u) {
             atomicAdd(visit_totals, n);
             atomicAdd(visit_totals + 1, t);
+            atomicAdd(visit_totals + 2, (unsigned long long)inner_steps);
+            atomicAdd(visit_totals + 3, (unsigned long long)leaf_steps);
+            atomicAdd(visit_totals + 4, (unsigned long long)leaf_rounds);
         }
     }
 }

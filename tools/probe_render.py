@@ -1,17 +1,38 @@
-import sys, time, json, os
-import numpy as np
-sys.path.insert(0, '.'); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import pathtracing_amd as P
-from pathtracing_amd import synth
-out = '/tmp/dragon_probe'
-t0 = time.time(); tp = synth.write_dragon_scene(out, 'scene_data'); print('gen', time.time() - t0, flush=True)
+"""Dragon frame timing for kernel experiments: python3 tools/probe_render.py [iterations]
+Prints the best of three renders (two batches in flight, as a default render), the same with one
+batch at a time, and the summed search_kernel time of a profiled single-stream render."""
+import os
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import pathtracing_amd as P  # noqa: E402
+from pathtracing_amd import synth  # noqa: E402
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+out = os.path.join(tempfile.gettempdir(), "pathtracing_amd_dragon")
+tp = synth.write_dragon_scene(out, os.path.join(ROOT, "scene_data"))
 task = P.RenderTask.from_json(open(tp).read())
-t0 = time.time(); sc = P.Scene.load(out, task.scene); print('load', time.time() - t0, flush=True)
-t0 = time.time(); r = P.HipRenderer.init(sc, 0); print('init(bvh+upload)', time.time() - t0, flush=True)
-for it in (1, 8, 64):
-    task.config.iterations = it
-    for rep in range(2):
-        t0 = time.time(); img = r.render(task, P.RenderOpts(seed=0, profile=(rep == 1))); dt = time.time() - t0
-        s = r.last_stats
-        print(f'iters={it} wall={dt:.3f}s render_ms={s.render_ms:.1f} rays={s.rays} Mrays/s={s.rays / s.render_ms / 1e3:.1f} '
-              f'search_ms={s.search_kernel_ms:.1f} launches={s.search_kernel_launches} searches={s.searches} mean={img.mean():.4f}', flush=True)
+task.config.iterations = iters
+r = P.HipRenderer.init(P.Scene.load(out, task.scene), 0)
+
+
+def best(opts, n=3):
+    r.render(task, opts)
+    ms = 1e9
+    for _ in range(n):
+        r.render(task, opts)
+        ms = min(ms, r.last_stats.render_ms)
+    return ms, r.last_stats
+
+
+ms2, s = best(P.RenderOpts(seed=0))
+ms1, _ = best(P.RenderOpts(seed=0, paths_per_batch=128 << 20, single_stream=True))
+_, sp = best(P.RenderOpts(seed=0, paths_per_batch=128 << 20, profile=True), n=1)
+_, sc = best(P.RenderOpts(seed=0, paths_per_batch=128 << 20, count_visits=True), n=1)
+print(f"lib={os.path.basename(P._native.LIB_PATH)} iters={iters} rays={s.rays} default_ms={ms2:.2f} ({s.rays / ms2 / 1e3:.0f} Mrays/s) "
+      f"one_batch_ms={ms1:.2f} search_kernel_ms={sp.search_kernel_ms:.2f} other_ms={sp.render_ms - sp.search_kernel_ms:.2f} "
+      f"nodes/search={sc.node_visits / sc.searches:.2f} tris/search={sc.triangle_tests / sc.searches:.2f} "
+      f"lanes/node_step={sc.node_visits / max(sc.wave_node_steps, 1):.1f} lanes/tri_round={sc.triangle_tests / max(sc.wave_leaf_rounds, 1):.1f} "
+      f"node_steps={sc.wave_node_steps} leaf_steps={sc.wave_leaf_steps} tri_rounds={sc.wave_leaf_rounds}", flush=True)
