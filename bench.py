@@ -211,7 +211,7 @@ def hbm_regime_record(P, N, synth, scene_dir, device, torch):
     rec["mrays_per_s"] = timed.rays / timed.render_ms / 1e3
     rec["scene_setup_s"] = setup_s
     t = recorded("hbm_traffic_flattened.json")
-    rec["traffic"] = t.get("bytes_per_launch") if t else None
+    rec["traffic"] = t["bytes_per_frame"] / rec["launches"] if t and t.get("bytes_per_frame") else None
     return rec
 
 
@@ -365,15 +365,16 @@ def main():
             roofline = search_kernel_record(P, renderer, sub, o, accum.data_ptr(), stream)
             torch.cuda.synchronize()
             if roofline is not None:
-                t = recorded("hbm_traffic.json") if args.config == "c3" else None
-                roofline["traffic"] = t.get("bytes_per_launch") if t else None
+                # recorded per frame (rocprofv3 PMC passes over the same frame), divided by this run's launches per frame
+                t = recorded("hbm_traffic.json") if args.config == "c3" and not multi else None
+                roofline["traffic"] = t["bytes_per_frame"] / roofline["launches"] if t and t.get("bytes_per_frame") else None
                 # the working set (nodes + leaf triangles) against the 256 MiB Infinity Cache: below it the records are
                 # re-read from cache and the figure above is a rate of cache traffic, bounded by the HBM peak only by name
                 roofline["cache_resident"] = roofline["bvh_bytes"] < 256 * 2**20
-                sq = recorded("sq_counters.json") if args.config == "c3" else None
-                if sq and sq.get("search_kernel"):
+                sq = recorded("sq_counters.json") if args.config == "c3" and not multi else None
+                if sq and sq.get("search_kernel") and sq["search_kernel"].get("valu_insts_per_frame"):
                     k = sq["search_kernel"]
-                    insts = k["valu_insts_per_launch"]
+                    insts = k["valu_insts_per_frame"] / roofline["launches"]
                     roofline["issue"] = {"bound": "valu", "achieved": insts / (roofline["launch_ms"] * 1e-3), "peak": VALU_PEAK_PER_S,
                                          "unit": "wave64 VALU instructions/s",
                                          "frac": insts / (roofline["launch_ms"] * 1e-3) / VALU_PEAK_PER_S,

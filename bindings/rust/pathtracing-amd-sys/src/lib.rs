@@ -260,6 +260,10 @@ pub struct PtHostScene {
 pub struct PtFrame {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct PtWorker {
+    _private: [u8; 0],
+}
 
 extern "C" {
     pub fn pt_last_error(buf: *mut c_char, cap: usize) -> usize;
@@ -374,6 +378,21 @@ extern "C" {
         out_cap_floats: usize,
     ) -> PtStatus;
 
+    pub fn pt_discovery_request_encode(out: *mut u8, cap: usize, out_len: *mut usize) -> PtStatus;
+    pub fn pt_discovery_request_decode(bytes: *const u8, len: usize) -> PtStatus;
+    pub fn pt_discovery_response_encode(websocket_port: u16, out: *mut u8, cap: usize, out_len: *mut usize) -> PtStatus;
+    pub fn pt_discovery_response_decode(bytes: *const u8, len: usize, out_websocket_port: *mut u16) -> PtStatus;
+    pub fn pt_scene_md5(root_dir: *const c_char, scene_path: *const c_char, out_hex33: *mut c_char) -> PtStatus;
+    pub fn pt_worker_create(store_root: *const c_char, device: c_int, out_worker: *mut *mut PtWorker) -> PtStatus;
+    pub fn pt_worker_destroy(worker: *mut PtWorker);
+    pub fn pt_worker_cached_scene_count(worker: *const PtWorker) -> u32;
+    pub fn pt_worker_handle_message(
+        worker: *mut PtWorker,
+        task_json: *const c_char,
+        opts: *const PtRenderOpts,
+        out_bytes: *mut *mut u8,
+        out_size: *mut u64,
+    ) -> PtStatus;
     pub fn pt_frame_create(width: u32, height: u32, device: c_int, out_frame: *mut *mut PtFrame) -> PtStatus;
     pub fn pt_frame_destroy(frame: *mut PtFrame);
     pub fn pt_frame_add_render(frame: *mut PtFrame, rgb: *const f32) -> PtStatus;

@@ -411,6 +411,43 @@ PtStatus pt_rendered_image_to_bytes(const float* rgb, uint32_t width, uint32_t h
 PtStatus pt_rendered_image_from_bytes(const uint8_t* bytes, size_t size, uint32_t* out_width,
                                       uint32_t* out_height, float* out_rgb, size_t out_cap_floats);
 
+/* -------------------------------------- the worker's front end, without sockets */
+
+/* worker::discovery::{Request, Response} (worker/src/lib.rs:81-91) in the wire format the
+ * reference uses for them, postcard 1.1: the worker answers every datagram on UDP port
+ * 40000 that decodes as a Request with a Response naming its WebSocket port
+ * (worker/src/main.rs:95-113; the client's side is client/src/worker_pool.rs:137-157).
+ * `Request {}` is zero bytes; `Response { websocket_port: u16 }` is the port as an LEB128
+ * varint (30000 = B0 EA 01).  Decoders ignore trailing bytes like postcard::from_bytes. */
+PtStatus pt_discovery_request_encode(uint8_t* out, size_t cap, size_t* out_len);
+PtStatus pt_discovery_request_decode(const uint8_t* bytes, size_t len);
+PtStatus pt_discovery_response_encode(uint16_t websocket_port, uint8_t* out, size_t cap, size_t* out_len);
+PtStatus pt_discovery_response_decode(const uint8_t* bytes, size_t len, uint16_t* out_websocket_port);
+
+/* The digest the client names a scene's file bucket with (client/src/scene.rs:19-85): MD5
+ * of every file the scene refers to, sorted by path, folded into one; 32 lower-case hex
+ * digits and a NUL into out_hex33.  kd_tree files are left out (the client stops at them
+ * with unimplemented!(), scene.rs:59-61; here they are a cache, not scene content). */
+PtStatus pt_scene_md5(const char* root_dir, const char* scene_path, char* out_hex33);
+
+/* Worker (worker/src/lib.rs:18-49): scenes cached by scene_md5, files fetched from the
+ * scene's bucket -- here the directory store_root + "/" + scene_md5 instead of the GridFS
+ * bucket of that name (file_store.rs:12-35); a task without scene_md5 (the file form,
+ * render_task.rs:5-10) reads store_root itself.  Missing or stale .tree files of a bucket
+ * are written back on the first load. */
+typedef struct PtWorker PtWorker;
+PtStatus pt_worker_create(const char* store_root, int device, PtWorker** out_worker);
+void pt_worker_destroy(PtWorker* worker);
+uint32_t pt_worker_cached_scene_count(const PtWorker* worker);
+
+/* One round of connection_loop (worker/src/main.rs:68-93) without the socket: task_json is
+ * the text frame (a RenderTask), *out_bytes / *out_size the binary frame sent back
+ * (RenderedImage::to_bytes, lib.rs:56-62; release with pt_buffer_free).  A frame that does
+ * not decode is PT_ERR_PARSE with the reference's "Failed to decode render task" message;
+ * the reference then drops the connection.  opts may be NULL. */
+PtStatus pt_worker_handle_message(PtWorker* worker, const char* task_json, const PtRenderOpts* opts,
+                                  uint8_t** out_bytes, uint64_t* out_size);
+
 /* ------------------------------------------------- the client's frame sum */
 
 /* Frame / RenderSum (client/src/frame.rs:11-15,54-58): the element-wise sum of

@@ -240,6 +240,16 @@ SYMBOLS = {
         C.c_int,
         [_VOIDP, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _VOIDP, C.c_size_t],
     ),
+    "pt_discovery_request_encode": (C.c_int, [_VOIDP, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "pt_discovery_request_decode": (C.c_int, [_VOIDP, C.c_size_t]),
+    "pt_discovery_response_encode": (C.c_int, [C.c_uint16, _VOIDP, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "pt_discovery_response_decode": (C.c_int, [_VOIDP, C.c_size_t, C.POINTER(C.c_uint16)]),
+    "pt_scene_md5": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p]),
+    "pt_worker_create": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_VOIDP)]),
+    "pt_worker_destroy": (None, [_VOIDP]),
+    "pt_worker_cached_scene_count": (C.c_uint32, [_VOIDP]),
+    "pt_worker_handle_message": (C.c_int, [_VOIDP, C.c_char_p, C.POINTER(PtRenderOpts), C.POINTER(C.POINTER(C.c_uint8)),
+                                          C.POINTER(C.c_uint64)]),
     "pt_frame_create": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_VOIDP)]),
     "pt_frame_destroy": (None, [_VOIDP]),
     "pt_frame_add_render": (C.c_int, [_VOIDP, _VOIDP]),

@@ -19,6 +19,7 @@
 
 #include "../../include/pathtracing_amd.h"
 #include "host/bvh.hpp"
+#include "host/front_end.hpp"
 #include "host/host_scene.hpp"
 #include "host/xform.hpp"
 #include "kernels/pt_kernels.h"
@@ -880,8 +881,57 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
 } // namespace
 
 
-// ------------------------------------------------------------ several GPUs, one process
+// ---------------------------------------------------------------------- .tree cache, worker
 namespace {
+
+// The write side of the .tree cache: every kd_tree node directly above a mesh node whose file is missing, empty
+// or not valid for the mesh gets its tree built, written through `store` and taken into the loaded scene.
+uint32_t cache_trees(pt::HostScene& hs, const pt::FileStore& store) {
+    uint32_t written = 0;
+    std::vector<uint8_t> settled(hs.trees.size(), 0); // this call has dealt with the file (one mesh per file)
+    for (size_t i = 0; i + 1 < hs.nodes.size(); i++) {
+        const PtNodeDesc& nd = hs.nodes[i];
+        if (nd.type != PT_NODE_KD_TREE || hs.nodes[i + 1].type != PT_NODE_MESH || nd.tree_id == PT_NO_INDEX) continue;
+        const uint32_t t = nd.tree_id, m = hs.nodes[i + 1].mesh_id;
+        if (t >= hs.trees.size() || m >= hs.meshes.size() || settled[t]) continue;
+        settled[t] = 1;
+        const pt::HostMesh& mesh = hs.meshes[m];
+        if (mesh.triangle_count == 0) continue;
+        pt::BuiltBvh bvh;
+        if (!hs.trees[t].empty() &&
+            pt::deserialize_tree(hs.trees[t].data(), hs.trees[t].size(), mesh.positions.data(), mesh.triangle_count, &bvh))
+            continue; // a hit: nothing to write
+        bvh = pt::build_bvh(mesh.positions.data(), mesh.triangle_count, 4);
+        std::vector<uint8_t> blob = pt::serialize_tree(bvh, mesh.positions.data(), mesh.triangle_count);
+        store.write_file(hs.tree_paths[t], blob);
+        hs.trees[t] = std::move(blob);
+        written++;
+    }
+    hs.finalize(); // the description's blob table points at the new contents
+    return written;
+}
+
+} // namespace
+
+// Worker (worker/src/lib.rs:18-49) with the FileStore (file_store.rs:12-35) over a directory: the bucket of
+// a scene is the sub-directory named by its scene_md5.
+struct PtWorker {
+    std::string store_root;
+    int device = 0;
+    std::mutex mu; // the reference keeps its Worker behind a mutex held across the render (main.rs:32,82)
+    struct Entry {
+        std::unique_ptr<pt::HostScene> host;
+        PtScene* scene = nullptr;
+    };
+    std::map<std::string, Entry> cached_scenes; // lib.rs:20: keyed by scene_md5
+    ~PtWorker() {
+        for (auto& kv : cached_scenes) pt_scene_destroy(kv.second.scene);
+    }
+};
+
+namespace {
+
+// ------------------------------------------------------------ several GPUs, one process
 
 // The share of `rank` of `world` (the split pathtracing_amd/distributed.py makes for the one-process-per-GPU path).
 // Sample ranges are contiguous and disjoint, the first `iterations % world` ranks get one sample more; row bands are
@@ -1364,6 +1414,120 @@ PtStatus pt_render_multi(PtScene** scenes, int n_devices, const PtRenderTask* ta
     return guarded([&] { render_multi(scenes, n_devices, task, opts, mode, out_rgb, stats); });
 }
 
+PtStatus pt_discovery_request_encode(uint8_t* out, size_t cap, size_t* out_len) {
+    return guarded([&] {
+        (void)out;
+        (void)cap;
+        if (!out_len) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        *out_len = 0; // `struct Request {}` (lib.rs:84-85) has no fields: postcard writes nothing
+    });
+}
+
+PtStatus pt_discovery_request_decode(const uint8_t* bytes, size_t len) {
+    (void)bytes;
+    (void)len;
+    return PT_OK; // nothing to read, trailing bytes are ignored (main.rs:104 hands postcard the whole datagram)
+}
+
+PtStatus pt_discovery_response_encode(uint16_t websocket_port, uint8_t* out, size_t cap, size_t* out_len) {
+    return guarded([&] {
+        if (!out || !out_len) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        std::vector<uint8_t> bytes = pt::discovery_response_encode(websocket_port);
+        if (cap < bytes.size()) throw Error(PT_ERR_INVALID_ARGUMENT, "output buffer too small (three bytes always suffice)");
+        memcpy(out, bytes.data(), bytes.size());
+        *out_len = bytes.size();
+    });
+}
+
+PtStatus pt_discovery_response_decode(const uint8_t* bytes, size_t len, uint16_t* out_websocket_port) {
+    return guarded([&] {
+        if ((len && !bytes) || !out_websocket_port) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        if (!pt::discovery_response_decode(bytes, len, out_websocket_port))
+            throw Error(PT_ERR_PARSE, "not a postcard-encoded discovery::Response (bad or truncated varint)");
+    });
+}
+
+PtStatus pt_scene_md5(const char* root_dir, const char* scene_path, char* out_hex33) {
+    return guarded([&] {
+        if (!root_dir || !scene_path || !out_hex33) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        std::string digest = pt::scene_md5(pt::FileStore(root_dir), scene_path);
+        memcpy(out_hex33, digest.c_str(), 33);
+    });
+}
+
+PtStatus pt_worker_create(const char* store_root, int device, PtWorker** out_worker) {
+    return guarded([&] {
+        if (!store_root || !out_worker) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        auto w = std::make_unique<PtWorker>();
+        w->store_root = store_root;
+        w->device = device;
+        *out_worker = w.release();
+    });
+}
+
+void pt_worker_destroy(PtWorker* worker) { delete worker; }
+
+uint32_t pt_worker_cached_scene_count(const PtWorker* worker) { return worker ? (uint32_t)worker->cached_scenes.size() : 0u; }
+
+PtStatus pt_worker_handle_message(PtWorker* worker, const char* task_json, const PtRenderOpts* opts, uint8_t** out_bytes,
+                                  uint64_t* out_size) {
+    PtStatus nested = PT_OK; // a failure of an entry point called from here: its message is already in place
+    PtStatus st = guarded([&] {
+        if (!worker || !task_json || !out_bytes || !out_size) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        std::lock_guard<std::mutex> lock(worker->mu);
+        // connection_loop, main.rs:68-93: a text frame holding the RenderTask ...
+        PtRenderTask task;
+        std::string scene_path, scene_md5;
+        try {
+            pt::parse_render_task(task_json, &task, &scene_path, &scene_md5);
+        } catch (const std::exception& e) {
+            throw Error(PT_ERR_PARSE, std::string("Failed to decode render task: ") + e.what());
+        }
+        // ... Worker::render, lib.rs:31-48: the scene from the cache, or loaded from its bucket
+        const std::string key = scene_md5.empty() ? "path:" + scene_path : scene_md5;
+        auto it = worker->cached_scenes.find(key);
+        if (it == worker->cached_scenes.end()) {
+            std::string root = worker->store_root;
+            if (!scene_md5.empty()) {
+                for (char c : scene_md5)
+                    if (!((c >= '0' && c <= '9') || (c >= 'a' && c <= 'f') || (c >= 'A' && c <= 'F')))
+                        throw Error(PT_ERR_INVALID_ARGUMENT, "scene_md5 is not a hex digest");
+                root += "/" + scene_md5;
+            }
+            pt::FileStore store(root);
+            PtWorker::Entry entry;
+            entry.host = pt::load_scene(store, scene_path);
+            try {
+                (void)cache_trees(*entry.host, store);
+            } catch (const Error& e) {
+                if (e.status != PT_ERR_IO) throw; // a read-only bucket is no reason to refuse the task
+            }
+            nested = pt_scene_create(&entry.host->desc, worker->device, &entry.scene);
+            if (nested != PT_OK) throw Error(nested, pt::last_error_string());
+            it = worker->cached_scenes.emplace(key, std::move(entry)).first;
+        }
+        const size_t floats = (size_t)task.camera.resolution_x * task.camera.resolution_y * 3;
+        if (task.camera.resolution_x > 0xFFFFFFFFull || task.camera.resolution_y > 0xFFFFFFFFull)
+            throw Error(PT_ERR_UNSUPPORTED, "resolution does not fit the result's u32 header");
+        // ... the image as the binary frame of RenderedImage::to_bytes, lib.rs:56-62
+        uint8_t* bytes = static_cast<uint8_t*>(malloc(8 + floats * sizeof(float) + 16));
+        if (!bytes) throw std::bad_alloc();
+        struct Guard {
+            uint8_t* p;
+            ~Guard() { free(p); }
+        } guard{bytes};
+        nested = pt_render(it->second.scene, &task, opts, reinterpret_cast<float*>(bytes + 8), nullptr);
+        if (nested != PT_OK) throw Error(nested, pt::last_error_string());
+        const uint32_t w = (uint32_t)task.camera.resolution_x, h = (uint32_t)task.camera.resolution_y;
+        memcpy(bytes, &w, 4); // little-endian target: the bytes are already in wire order
+        memcpy(bytes + 4, &h, 4);
+        *out_bytes = bytes;
+        *out_size = 8 + floats * sizeof(float);
+        guard.p = nullptr;
+    });
+    return st;
+}
+
 PtStatus pt_frame_create(uint32_t width, uint32_t height, int device, PtFrame** out_frame) {
     return guarded([&] {
         if (!out_frame) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
@@ -1558,29 +1722,7 @@ PtStatus pt_host_scene_load(const char* root_dir, const char* scene_path, PtHost
 PtStatus pt_host_scene_cache_trees(PtHostScene* scene, const char* root_dir, uint32_t* out_written) {
     return guarded([&] {
         if (!scene || !scene->scene || !root_dir) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
-        pt::HostScene& hs = *scene->scene;
-        pt::FileStore store(root_dir);
-        uint32_t written = 0;
-        std::vector<uint8_t> settled(hs.trees.size(), 0); // this call has dealt with the file (one mesh per file)
-        for (size_t i = 0; i + 1 < hs.nodes.size(); i++) {
-            const PtNodeDesc& nd = hs.nodes[i];
-            if (nd.type != PT_NODE_KD_TREE || hs.nodes[i + 1].type != PT_NODE_MESH || nd.tree_id == PT_NO_INDEX) continue;
-            const uint32_t t = nd.tree_id, m = hs.nodes[i + 1].mesh_id;
-            if (t >= hs.trees.size() || m >= hs.meshes.size() || settled[t]) continue;
-            settled[t] = 1;
-            const pt::HostMesh& mesh = hs.meshes[m];
-            if (mesh.triangle_count == 0) continue;
-            pt::BuiltBvh bvh;
-            if (!hs.trees[t].empty() &&
-                pt::deserialize_tree(hs.trees[t].data(), hs.trees[t].size(), mesh.positions.data(), mesh.triangle_count, &bvh))
-                continue; // a hit: nothing to write
-            bvh = pt::build_bvh(mesh.positions.data(), mesh.triangle_count, 4);
-            std::vector<uint8_t> blob = pt::serialize_tree(bvh, mesh.positions.data(), mesh.triangle_count);
-            store.write_file(hs.tree_paths[t], blob);
-            hs.trees[t] = std::move(blob);
-            written++;
-        }
-        hs.finalize(); // the description's blob table points at the new contents
+        uint32_t written = cache_trees(*scene->scene, pt::FileStore(root_dir));
         if (out_written) *out_written = written;
     });
 }

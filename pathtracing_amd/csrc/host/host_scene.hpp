@@ -72,6 +72,9 @@ HostImage decode_png(const uint8_t* data, size_t size);
 std::unique_ptr<HostScene> load_scene(const FileStore& store, const std::string& scene_path);
 
 // api/render_task.rs:5-29.
-void parse_render_task(const std::string& json_text, PtRenderTask* out, std::string* scene_path);
+// `scene_md5` (may be null) receives the wire form's field of that name, or "" for the file form
+// (RenderTaskUninit, render_task.rs:5-10).
+void parse_render_task(const std::string& json_text, PtRenderTask* out, std::string* scene_path,
+                       std::string* scene_md5 = nullptr);
 
 } // namespace pt

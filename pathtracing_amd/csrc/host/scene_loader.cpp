@@ -309,10 +309,14 @@ std::unique_ptr<HostScene> load_scene(const FileStore& store, const std::string&
     return scene;
 }
 
-void parse_render_task(const std::string& json_text, PtRenderTask* out, std::string* scene_path) {
+void parse_render_task(const std::string& json_text, PtRenderTask* out, std::string* scene_path, std::string* scene_md5) {
     Value v = ptjson::parse(json_text);
     memset(out, 0, sizeof(*out));
     if (scene_path) *scene_path = as_string(field(v, "scene", "render task"), "render task scene");
+    if (scene_md5) {
+        const Value* md5 = v.kind == Value::Object ? v.find("scene_md5") : nullptr;
+        *scene_md5 = md5 ? as_string(*md5, "render task scene_md5") : std::string();
+    }
     const Value& config = field(v, "config", "render task");
     out->trace_depth = as_usize(field(config, "trace_depth", "config"), "config.trace_depth");
     out->iterations = as_usize(field(config, "iterations", "config"), "config.iterations");

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "pathtracing_amd.h")
 CRATE = os.path.join(ROOT, "bindings", "rust", "pathtracing-amd-sys", "src", "lib.rs")
 
-SCALARS = {"float": "f32", "double": "f64", "uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize",
+SCALARS = {"float": "f32", "double": "f64", "uint8_t": "u8", "uint16_t": "u16", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize",
            "int": "c_int", "char": "c_char", "void": "c_void", "PtStatus": "PtStatus"}
 
 
@@ -99,7 +99,7 @@ def test_rust_structs_follow_the_header():
     for name, fields in c.items():
         assert name in r, f"struct {name} is missing from the crate"
         assert r[name] == fields, f"struct {name}: header {fields} / crate {r[name]}"
-    for opaque in ("PtScene", "PtHostScene", "PtFrame"):
+    for opaque in ("PtScene", "PtHostScene", "PtFrame", "PtWorker"):
         assert r[opaque] == [("_private", "[u8; 0]")]
 
 

@@ -31,7 +31,7 @@ with open(f"profiles/r{rnd}_sq_counters.txt", "w") as f:
         n = launches[k].get("SQ_INSTS_VALU", 0)
         if n:
             valu = agg[k]["SQ_INSTS_VALU"]
-            out[k] = {"launches": n, "valu_insts_per_launch": valu / n,
+            out[k] = {"launches": n, "valu_insts_per_launch": valu / n, "valu_insts_per_frame": valu,
                       "active_lane_share": agg[k]["SQ_THREAD_CYCLES_VALU"] / (64.0 * valu) if valu else None,
                       "salu_insts_per_launch": agg[k]["SQ_INSTS_SALU"] / n, "vmem_rd_insts_per_launch": agg[k]["SQ_INSTS_VMEM_RD"] / n,
                       "wait_any_share_of_wave_cycles": agg[k]["SQ_WAIT_ANY"] / agg[k]["SQ_WAVE_CYCLES"] if agg[k]["SQ_WAVE_CYCLES"] else None}

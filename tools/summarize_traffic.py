@@ -36,6 +36,7 @@ for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     n = sum(h[0] for h in hit)
     v = sum(h[1] for h in hit)
     out[counter] = {"launches": n, "sum_KiB": v, "mean_KiB_per_launch": v / n}
+renders = 2 if flattened else 1  # tools/probe_flattened.py renders the frame twice, tools/profile_render.py once
 fetch = out["FETCH_SIZE"]["mean_KiB_per_launch"] * 1024
 write = out["WRITE_SIZE"]["mean_KiB_per_launch"] * 1024
 if flattened:
@@ -62,6 +63,8 @@ json.dump({
     "fetch_bytes_per_launch_raw": fetch,
     "write_bytes_per_launch": write,
     "bytes_per_launch": total,
+    # per rendered frame (the launches of one frame together): what bench.py divides by its own launch count
+    "bytes_per_frame": total * out["FETCH_SIZE"]["launches"] / renders,
     "note": note,
 }, open(f"profiles/hbm_traffic{suffix}.json", "w"), indent=1)
 print(json.dumps(out))
