@@ -731,6 +731,21 @@ __device__ __forceinline__ void run_child_hit(const DScene& sc, uint32_t k, cons
     }
 }
 
+// The distance at which the run's child k reports the triangle hit at `t` in its mesh's space: the t of
+// run_child_hit's record (transform.rs:57-58 on the point of triangle_finish) without the rest of it.
+__device__ __forceinline__ float run_child_distance(const DScene& sc, uint32_t k, const Ray& world, float t) {
+    const RunChildIds ids = run_child_ids(sc.run, k);
+    if (ids.transform_node == kRunNoTransform) return t;
+    M4 inv, fwd;
+    M3 ninv, nfwd;
+    unpack_rows(global_f4(sc.run.children + k), 1, &inv, &ninv);
+    unpack_rows(global_f4(sc.run.children + k), 8, &fwd, &nfwd);
+    V3 source = mul_point(inv, world.source);
+    V3 direction = mul(ninv, world.direction);
+    V3 point = mul_point(fwd, source + direction * t);
+    return length(point - world.source);
+}
+
 // node_collection.rs:48-52 over the children of the run: `h` of child k replaces the
 // running best when it is closer, or as close and from an earlier child (the
 // sequential loop keeps the first of equals; the candidates arrive in any order).
@@ -766,18 +781,27 @@ __device__ __forceinline__ void walk_run(const DScene& sc, const Ray& world, con
     best.uv = mk2(0, 0);
     uint32_t best_k = 0xFFFFFFFFu;
     if (look != nullptr && look->head != kRunInPlace) {
+        // which child wins needs only each candidate's distance; the winner's record is built once
         GlobalF4Ptr jobs = global_f4(look->job_c), results = global_f4(look->run_res);
         uint32_t j = look->head;
+        float win_t = f32_inf(), win_local_t = 0.0f;
+        uint32_t win_slot = 0u, win_orig = 0u;
         while (j != kRunNone) {
             const float4 jc = jobs[(int)j], res = results[(int)j];
             if (__float_as_uint(res.y) != 0u) {
                 const uint32_t k = __float_as_uint(jc.z) & ~kRunJobFlag;
-                Hit h;
-                run_child_hit(sc, k, world, res.x, __float_as_uint(res.z), __float_as_uint(res.w), &h);
-                run_take(best, best_k, h, k);
+                const float t = run_child_distance(sc, k, world, res.x);
+                if (t < win_t || (best_k != 0xFFFFFFFFu && t == win_t && k < best_k)) {
+                    win_t = t;
+                    best_k = k;
+                    win_local_t = res.x;
+                    win_slot = __float_as_uint(res.z);
+                    win_orig = __float_as_uint(res.w);
+                }
             }
             j = __float_as_uint(jc.w);
         }
+        if (best_k != 0xFFFFFFFFu) run_child_hit(sc, best_k, world, win_local_t, win_slot, win_orig, &best);
     } else {
         RunCursor c;
         run_begin(sc.run, world, true, c);
