@@ -52,6 +52,13 @@ public:
     Scene(const Scene&) = delete;
     Scene& operator=(const Scene&) = delete;
     const PtSceneDesc* desc() const { return pt_host_scene_desc(handle_); }
+    // Writes the .tree file of every kd_tree node whose file is missing or does not fit its mesh and takes
+    // it into this scene (kd_tree.rs:12-51 names the file; nothing upstream writes it). Returns how many.
+    uint32_t cache_trees(const std::string& root_dir) {
+        uint32_t written = 0;
+        check(pt_host_scene_cache_trees(handle_, root_dir.c_str(), &written));
+        return written;
+    }
 
 private:
     explicit Scene(PtHostScene* h) : handle_(h) {}
@@ -156,6 +163,13 @@ public:
         check(pt_render(handle_, &task.task, opts, img.rgb.data(), stats));
         return img;
     }
+    // What pt_scene_create did: .tree files offered / adopted, structures built, times.
+    PtSceneInfo info() const {
+        PtSceneInfo out{};
+        check(pt_scene_info(handle_, &out));
+        return out;
+    }
+    PtScene* handle() const { return handle_; }
 
 private:
     HipRenderer(PtScene* h, std::shared_ptr<const Scene> s) : handle_(h), scene_(std::move(s)) {}
@@ -184,6 +198,69 @@ private:
     std::string root_, scene_path_;
     int device_;
     std::unique_ptr<HipRenderer> renderer_;
+};
+
+// One task on several GPUs of this process: one renderer per device from the same scene, the task split by
+// sample range (PT_SHARD_SAMPLES) or bands of 8 pixel rows (PT_SHARD_ROWS), the partial sums reduced onto the
+// first device.  What worker_pool.rs:221-236 + frame.rs:60-84 do across workers, inside one worker.
+class MultiRenderer {
+public:
+    static MultiRenderer init(std::shared_ptr<const Scene> scene, const std::vector<int>& devices) {
+        MultiRenderer m;
+        for (int d : devices) m.renderers_.push_back(HipRenderer::init(scene, d));
+        return m;
+    }
+    RenderedImage render(const RenderTask& task, PtShardMode mode = PT_SHARD_SAMPLES, const PtRenderOpts* opts = nullptr,
+                         PtRenderStats* stats = nullptr) {
+        std::vector<PtScene*> handles;
+        for (const HipRenderer& r : renderers_) handles.push_back(r.handle());
+        RenderedImage img;
+        img.width = (uint32_t)task.task.camera.resolution_x;
+        img.height = (uint32_t)task.task.camera.resolution_y;
+        img.rgb.resize((size_t)img.width * img.height * 3);
+        check(pt_render_multi(handles.data(), (int)handles.size(), &task.task, opts, (uint32_t)mode, img.rgb.data(), stats));
+        return img;
+    }
+
+private:
+    std::vector<HipRenderer> renderers_;
+};
+
+// The worker's front end without its sockets (worker/src/main.rs:36-113): the discovery reply and one round of
+// connection_loop over a store of directories named by scene_md5 (file_store.rs:17-23).
+inline std::vector<uint8_t> discovery_response(uint16_t websocket_port) { // lib.rs:86-91, main.rs:104-110
+    uint8_t buf[8];
+    size_t n = 0;
+    check(pt_discovery_response_encode(websocket_port, buf, sizeof(buf), &n));
+    return std::vector<uint8_t>(buf, buf + n);
+}
+inline bool is_discovery_request(const uint8_t* datagram, size_t size) { // lib.rs:83-84: `Request {}` is the empty message
+    return pt_discovery_request_decode(datagram, size) == PT_OK;
+}
+inline std::string scene_md5(const std::string& root_dir, const std::string& scene_path) { // client/src/scene.rs:19-85
+    char hex[33];
+    check(pt_scene_md5(root_dir.c_str(), scene_path.c_str(), hex));
+    return std::string(hex);
+}
+class WorkerFrontEnd {
+public:
+    explicit WorkerFrontEnd(const std::string& store_root, int device = 0) { check(pt_worker_create(store_root.c_str(), device, &handle_)); }
+    WorkerFrontEnd(const WorkerFrontEnd&) = delete;
+    WorkerFrontEnd& operator=(const WorkerFrontEnd&) = delete;
+    ~WorkerFrontEnd() { pt_worker_destroy(handle_); }
+    // main.rs:68-93: a text frame holding a RenderTask in, the RenderedImage bytes of the reply out
+    std::vector<uint8_t> handle_message(const std::string& task_json, const PtRenderOpts* opts = nullptr) {
+        uint8_t* bytes = nullptr;
+        uint64_t size = 0;
+        check(pt_worker_handle_message(handle_, task_json.c_str(), opts, &bytes, &size));
+        std::vector<uint8_t> out(bytes, bytes + size);
+        pt_buffer_free(bytes);
+        return out;
+    }
+    uint32_t cached_scenes() const { return pt_worker_cached_scene_count(handle_); }
+
+private:
+    PtWorker* handle_ = nullptr;
 };
 
 } // namespace pt

@@ -12,6 +12,7 @@ from tests import helpers as H
 
 EXAMPLES = os.path.join(H.ROOT, "examples")
 BINARY = os.path.join(EXAMPLES, "render_task")
+FRONT_END = os.path.join(EXAMPLES, "worker_front_end")
 
 
 def small_task(tmp_path, scene="./scene.json"):
@@ -35,6 +36,15 @@ def test_example_builds_and_reports_errors(tmp_path):
     assert r.returncode == 1 and "no_such_scene" in r.stderr
     r = subprocess.run([BINARY], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr
+    # the front end's pure functions through the C++ mirror: postcard bytes of the discovery reply, the scene digest
+    assert os.path.exists(FRONT_END)
+    assert subprocess.check_output([FRONT_END, "discovery"], text=True).strip() == "b0ea01"  # WEBSOCKET_PORT 30000
+    assert subprocess.check_output([FRONT_END, "discovery", "300"], text=True).strip() == "ac02"
+    from pathtracing_amd import front_end as F
+    got = subprocess.check_output([FRONT_END, "digest", H.SCENE_DATA, "./simple_scene.json"], text=True).strip()
+    assert got == F.scene_md5(H.SCENE_DATA, "./simple_scene.json")
+    r = subprocess.run([FRONT_END, "digest", H.SCENE_DATA, "./missing.json"], capture_output=True, text=True)
+    assert r.returncode == 1 and "missing" in r.stderr
 
 
 @pytest.mark.gpu
@@ -53,3 +63,36 @@ def test_example_renders_the_same_bytes_as_the_python_worker(tmp_path):
         got = f.read()
     assert got == want
     assert np.frombuffer(got[8:], dtype="<f4").reshape(32, 48, 3).mean() > 0
+
+
+@pytest.mark.gpu
+def test_front_end_example_serves_a_task_and_splits_it(tmp_path):
+    import shutil
+    from pathtracing_amd import front_end as F
+    assert os.path.exists(FRONT_END), "examples/worker_front_end is built by __graft_entry__.build()"
+    store = str(tmp_path / "store")
+    os.makedirs(store)
+    md5 = F.scene_md5(H.SCENE_DATA, "./scene.json")
+    shutil.copytree(H.SCENE_DATA, os.path.join(store, md5))
+    task_path = small_task(tmp_path)
+    with open(task_path) as f:
+        wire = json.load(f)
+    wire["scene_md5"] = md5
+    wire_path = str(tmp_path / "wire.json")
+    with open(wire_path, "w") as f:
+        json.dump(wire, f)
+    with open(task_path) as f:
+        task = P.RenderTask.from_json(f.read())
+    want = P.RenderedImage(P.Worker(H.SCENE_DATA).render(task, P.RenderOpts(seed=5))).to_bytes()
+    out = str(tmp_path / "reply.bin")
+    r = subprocess.run([FRONT_END, "serve", store, wire_path, out, "5"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "1 scene(s) cached" in r.stdout
+    with open(out, "rb") as f:
+        assert f.read() == want
+    # three renderers, three bands of rows, one sum: the same bytes
+    out = str(tmp_path / "multi.bin")
+    r = subprocess.run([FRONT_END, "multi", H.SCENE_DATA, task_path, out, "3", "5"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    with open(out, "rb") as f:
+        assert f.read() == want
