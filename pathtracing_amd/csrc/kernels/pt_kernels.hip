@@ -350,11 +350,12 @@ inject_kernel(DScene scene, const PtRay* __restrict__ rays, uint32_t n, SegmentB
 // the remaining meshes in place.  kFlat: the scene has a flat root (walk_flat);
 // otherwise the general resumable walk.
 // Waves per SIMD the kernel is compiled for: four without the instance-run code (128 registers:
-// the loop over a flat root's children and the general walk both fit), three with it.
+// the loop over a flat root's children and the general walk both fit, and so does the flat loop with the
+// run code); three for the general walk with the run code.
 // kFull: the whole hit record of every ray goes to full_hits[path id] as well (the closest-hit
 // contract on the wavefront route; a render needs only what the bounce reads).
 template <bool kRun, bool kFlat, bool kFull = false>
-__global__ void __launch_bounds__(kBlock, kRun ? 3 : 4)
+__global__ void __launch_bounds__(kBlock, kRun && !kFlat ? 3 : 4)
 walk_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions, unsigned long long* ray_total,
             uint32_t* spill, uint32_t spill_threads, PtHit* full_hits = nullptr) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
@@ -453,7 +454,7 @@ walk_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions, un
 // wave's region of the other queue, or the path's final colour into the
 // contribution buffer.
 #ifndef PT_BOUNCE_OCCUPANCY
-#define PT_BOUNCE_OCCUPANCY 4
+#define PT_BOUNCE_OCCUPANCY 5
 #endif
 template <bool kRun>
 __global__ void __launch_bounds__(kBlock, PT_BOUNCE_OCCUPANCY)
@@ -582,12 +583,14 @@ bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList sl, u
 // ------------------------------------------------------- walk + bounce in one
 // Scenes with a flat root and no instance run: walk_flat and the bounce in one kernel, the hit
 // staying in registers (the two kernels hand each other 36 bytes per ray through memory, and the
-// bounce is bound by its memory traffic).  168 registers, three waves per SIMD; fetching the next
-// chunk's records ahead, as bounce_kernel does, costs more in spills than it hides here.  Scenes with an instance run keep the two kernels: the
+// bounce is bound by its memory traffic).  Four waves per SIMD: built without the SLP vectoriser (its
+// packed two-float operations want aligned register pairs and the moves to form them) the kernel needs
+// 135 registers, and held to 128 it spills one; fetching the next chunk's records ahead, as
+// bounce_kernel does, costs more in spills than it hides here.  Scenes with an instance run keep the two kernels: the
 // walk reads the segment's job list while the bounce overwrites it with the next segment's.
 // kFull: as in walk_kernel.
 #ifndef PT_WALK_BOUNCE_OCCUPANCY
-#define PT_WALK_BOUNCE_OCCUPANCY 3
+#define PT_WALK_BOUNCE_OCCUPANCY 4
 #endif
 template <bool kFull = false>
 __global__ void __launch_bounds__(kBlock, PT_WALK_BOUNCE_OCCUPANCY)
