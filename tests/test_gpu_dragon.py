@@ -117,3 +117,54 @@ def test_dragon_rays_along_coordinate_planes(dragon):
     H.assert_hits_identical(got, gpu.trace_closest(rays, brute_force=True), "axis-parallel rays: BVH vs scan")
     H.assert_all_routes(gpu, rays, cpu.trace(rays, accel=ob.ACCEL_BVH, math=ob.MATH_PORTABLE), "axis-parallel rays vs oracle")
     assert ((got["hit"] == 1) & (got["tri_index"] != 0xFFFFFFFF)).mean() > 0.5
+
+
+def test_visit_counters_are_consistent_and_do_not_change_the_image(dragon):
+    """PT_FLAG_COUNT_VISITS: the node and triangle records the search kernel fetches (the measured side of the
+    benchmark's byte count) and its wave-level steps.  Counting runs another instance of the kernel: same image."""
+    task, gpu, cpu = dragon
+    old = (list(task.camera.resolution), task.config.trace_depth, task.config.iterations)
+    task.camera.resolution = [320, 184]
+    task.config = P.Config(trace_depth=4, iterations=4)
+    try:
+        plain = gpu.render(task, P.RenderOpts(seed=2))
+        s0 = gpu.last_stats
+        assert (s0.node_visits, s0.triangle_tests, s0.wave_node_steps, s0.wave_leaf_steps, s0.wave_leaf_rounds) == (0, 0, 0, 0, 0)
+        counted = gpu.render(task, P.RenderOpts(seed=2, count_visits=True))
+        s1 = gpu.last_stats
+        assert np.array_equal(H.bits(plain), H.bits(counted))
+        assert s1.rays == s0.rays and s1.searches == s0.searches and s1.searches > 10_000
+        # every search opens the root; a step serves between one and 64 lanes; a leaf step lasts one to four rounds
+        assert s1.node_visits >= s1.searches
+        assert s1.wave_node_steps <= s1.node_visits <= 64 * s1.wave_node_steps
+        assert s1.wave_leaf_steps <= s1.wave_leaf_rounds <= 4 * s1.wave_leaf_steps
+        assert s1.wave_leaf_rounds <= s1.triangle_tests <= 64 * s1.wave_leaf_rounds
+        assert 4.0 < s1.node_visits / s1.searches < 60.0 and 1.0 < s1.triangle_tests / s1.searches < 60.0
+        # which lanes share a step depends on nothing but the job lists: a second count gives the same numbers
+        gpu.render(task, P.RenderOpts(seed=2, count_visits=True))
+        s2 = gpu.last_stats
+        assert (s2.node_visits, s2.triangle_tests, s2.wave_node_steps, s2.wave_leaf_rounds) == \
+               (s1.node_visits, s1.triangle_tests, s1.wave_node_steps, s1.wave_leaf_rounds)
+        # one batch at a time or two in flight: the same searches
+        gpu.render(task, P.RenderOpts(seed=2, count_visits=True, single_stream=True, paths_per_batch=1 << 16))
+        s3 = gpu.last_stats
+        assert (s3.node_visits, s3.triangle_tests) == (s1.node_visits, s1.triangle_tests)
+    finally:
+        task.camera.resolution, task.config.trace_depth, task.config.iterations = old[0], old[1], old[2]
+
+
+def test_visit_counters_on_a_tiny_tree():
+    """cube.obj: twelve triangles under a tree of one or two four-wide nodes.  Every search fetches the root once,
+    no node twice, and at most the twelve triangles."""
+    task = H.load_task()
+    task.scene = "./scene.json"
+    task.camera.resolution = [96, 64]
+    task.config = P.Config(trace_depth=5, iterations=3)
+    gpu = P.HipRenderer.init(P.Scene.load(H.SCENE_DATA, task.scene), 0)
+    gpu.render(task, P.RenderOpts(seed=1, count_visits=True))
+    s = gpu.last_stats
+    nodes = (s.bvh_bytes - 12 * 48) // 64
+    assert s.bvh_bytes == nodes * 64 + 12 * 48 and 1 <= nodes <= 2
+    assert s.searches > 1000 and s.searches <= s.node_visits <= nodes * s.searches
+    assert s.searches <= s.triangle_tests <= 12 * s.searches
+    gpu.close()
