@@ -14,7 +14,7 @@
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const PT_ABI_VERSION: u32 = 2;
+pub const PT_ABI_VERSION: u32 = 3;
 pub const PT_NO_INDEX: u32 = 0xFFFF_FFFF;
 pub const PT_FLAG_BRUTE_FORCE: u32 = 1;
 pub const PT_FLAG_PROFILE: u32 = 2;
@@ -231,6 +231,7 @@ pub struct PtRenderStats {
     pub wave_node_steps: u64,
     pub wave_leaf_steps: u64,
     pub wave_leaf_rounds: u64,
+    pub reduce_ms: f64,
 }
 
 #[repr(C)]

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 2u
+#define PT_ABI_VERSION 3u
 
 /* ------------------------------------------------------------------ status */
 
@@ -254,6 +254,7 @@ typedef struct PtRenderStats {
      * many rounds as its fullest leaf has triangles): node_visits / (64 * wave_node_steps) is the
      * share of lanes at work in a node step */
     uint64_t wave_node_steps, wave_leaf_steps, wave_leaf_rounds;
+    double reduce_ms;     /* pt_render_multi: host time of the sum onto the first device (0 elsewhere) */
 } PtRenderStats;
 
 /* Renderer::render (renderer/mod.rs:12) -> Rgb32FImage: fills out_rgb
@@ -302,8 +303,13 @@ PtStatus pt_shard(const PtRenderTask* task, const PtRenderOpts* opts, uint32_t m
  * un-normalised sums are added onto the first device -- one grouped RCCL reduce(sum) over
  * xGMI when the devices are distinct and RCCL can be opened, peer copies and adds
  * otherwise (and with PATHTRACING_AMD_REDUCE=p2p) -- which resolves the image into out_rgb
- * (host memory, layout as pt_render).  n_devices = 1 is pt_render.  stats (may be NULL):
- * rays, paths and searches summed over the devices, render_ms = the whole call. */
+ * (layout as pt_render; host memory, or memory of scenes[0]'s device, which saves the copy
+ * back).  n_devices = 1 is pt_render.  task->iterations = 0, and a tile in `opts` together
+ * with PT_SHARD_ROWS, are refused.  Streams, the per-device accumulation buffers and the
+ * communicators are kept per list of devices for later calls (pt_device_release_workspace
+ * frees the buffers); calls naming the same list of devices take turns.  stats (may be
+ * NULL): counters summed over the devices, render_ms = the call on the host's clock without
+ * that one-time set-up, reduce_ms = the part of it spent on the sum. */
 PtStatus pt_render_multi(PtScene** scenes, int n_devices, const PtRenderTask* task, const PtRenderOpts* opts,
                          uint32_t mode, float* out_rgb, PtRenderStats* stats);
 
@@ -432,9 +438,12 @@ PtStatus pt_scene_md5(const char* root_dir, const char* scene_path, char* out_he
 
 /* Worker (worker/src/lib.rs:18-49): scenes cached by scene_md5, files fetched from the
  * scene's bucket -- here the directory store_root + "/" + scene_md5 instead of the GridFS
- * bucket of that name (file_store.rs:12-35); a task without scene_md5 (the file form,
- * render_task.rs:5-10) reads store_root itself.  Missing or stale .tree files of a bucket
- * are written back on the first load. */
+ * bucket of that name (file_store.rs:12-35).  A task without scene_md5 (the file form,
+ * render_task.rs:5-10) is not a RenderTask and is refused like any frame that does not
+ * decode.  The scene name of a frame and the names inside the files it leads to are a
+ * peer's: a name that is absolute or has a ".." component is PT_ERR_INVALID_ARGUMENT, so
+ * nothing is read or written outside the bucket.  Missing or stale .tree files of a
+ * bucket are written back on the first load. */
 typedef struct PtWorker PtWorker;
 PtStatus pt_worker_create(const char* store_root, int device, PtWorker** out_worker);
 void pt_worker_destroy(PtWorker* worker);

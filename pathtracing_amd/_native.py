@@ -187,6 +187,7 @@ class PtRenderStats(C.Structure):
         ("wave_node_steps", C.c_uint64),
         ("wave_leaf_steps", C.c_uint64),
         ("wave_leaf_rounds", C.c_uint64),
+        ("reduce_ms", C.c_double),
     ]
 
 

@@ -888,6 +888,12 @@ namespace {
 // or not valid for the mesh gets its tree built, written through `store` and taken into the loaded scene.
 uint32_t cache_trees(pt::HostScene& hs, const pt::FileStore& store) {
     uint32_t written = 0;
+    // the description's blob table must point at the new contents however this function is left: a write that
+    // fails part-way (PT_ERR_IO, which callers may ignore) comes after earlier blobs have been replaced
+    struct Finalize {
+        pt::HostScene& hs;
+        ~Finalize() { hs.finalize(); }
+    } finalize{hs};
     std::vector<uint8_t> settled(hs.trees.size(), 0); // this call has dealt with the file (one mesh per file)
     for (size_t i = 0; i + 1 < hs.nodes.size(); i++) {
         const PtNodeDesc& nd = hs.nodes[i];
@@ -907,7 +913,6 @@ uint32_t cache_trees(pt::HostScene& hs, const pt::FileStore& store) {
         hs.trees[t] = std::move(blob);
         written++;
     }
-    hs.finalize(); // the description's blob table points at the new contents
     return written;
 }
 
@@ -1000,23 +1005,84 @@ Rccl& rccl() {
     return *r;
 }
 
-// One communicator set per device list, kept for the life of the process (setting one up takes seconds).
-std::vector<ncclComm_t>& communicators(const std::vector<int>& devices) {
-    static std::mutex mu;
-    static std::map<std::vector<int>, std::vector<ncclComm_t>>* cache = new std::map<std::vector<int>, std::vector<ncclComm_t>>();
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = cache->find(devices);
-    if (it != cache->end()) return it->second;
-    std::vector<ncclComm_t> comms(devices.size());
-    rccl().check(rccl().comm_init_all(comms.data(), (int)devices.size(), devices.data()), "ncclCommInitAll");
-    return (*cache)[devices] = comms;
-}
-
-// Per-device resources of one pt_render_multi call.
-struct Lane {
-    PtScene* scene = nullptr;
+// What pt_render_multi keeps between calls for one list of devices: a stream and an accumulation buffer per
+// entry of the list, the staging buffer of the peer-copy route and the resolved image on the first device.
+// Calls on the same list take turns (the buffers, and the communicators' order of operations, are shared).
+struct MultiSlot {
+    int device = 0;
     hipStream_t stream = nullptr;
     float* accum = nullptr;
+};
+struct MultiContext {
+    std::mutex mu;
+    std::vector<MultiSlot> slots;
+    size_t capacity = 0; // bytes of every buffer below
+    float* staging = nullptr;
+    float* resolved = nullptr;
+    std::vector<ncclComm_t> comms; // empty until the RCCL route is first taken
+};
+std::mutex& multi_registry_mu() {
+    static std::mutex mu;
+    return mu;
+}
+std::map<std::vector<int>, MultiContext*>& multi_registry() {
+    static auto* r = new std::map<std::vector<int>, MultiContext*>(); // never destroyed: the HIP runtime may be gone by then
+    return *r;
+}
+MultiContext& multi_context(const std::vector<int>& devices) {
+    std::lock_guard<std::mutex> lock(multi_registry_mu());
+    MultiContext*& c = multi_registry()[devices];
+    if (!c) {
+        c = new MultiContext();
+        c->slots.resize(devices.size());
+        for (size_t i = 0; i < devices.size(); i++) c->slots[i].device = devices[i];
+    }
+    return *c;
+}
+void free_multi_buffers(MultiContext& c) {
+    for (MultiSlot& s : c.slots) {
+        if (!s.accum) continue;
+        (void)hipSetDevice(s.device);
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        (void)hipFree(s.accum);
+        s.accum = nullptr;
+    }
+    if (!c.slots.empty()) (void)hipSetDevice(c.slots[0].device);
+    if (c.staging) (void)hipFree(c.staging);
+    if (c.resolved) (void)hipFree(c.resolved);
+    c.staging = c.resolved = nullptr;
+    c.capacity = 0;
+}
+// Frees the buffers of every device list that names `device` (streams and communicators stay).
+void release_multi_buffers(int device) {
+    std::vector<MultiContext*> hit;
+    {
+        std::lock_guard<std::mutex> lock(multi_registry_mu());
+        for (auto& kv : multi_registry())
+            if (std::find(kv.first.begin(), kv.first.end(), device) != kv.first.end()) hit.push_back(kv.second);
+    }
+    for (MultiContext* c : hit) {
+        std::lock_guard<std::mutex> lock(c->mu);
+        free_multi_buffers(*c);
+    }
+}
+void prepare_multi(MultiContext& c, size_t bytes, bool want_staging) {
+    if (bytes > c.capacity) free_multi_buffers(c);
+    const size_t cap = std::max<size_t>(std::max(bytes, c.capacity), 16);
+    for (MultiSlot& s : c.slots) {
+        hip_check(hipSetDevice(s.device), "hipSetDevice");
+        if (!s.stream) hip_check(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "hipStreamCreate");
+        if (!s.accum) hip_check(hipMalloc(reinterpret_cast<void**>(&s.accum), cap), "hipMalloc accumulation buffer");
+    }
+    hip_check(hipSetDevice(c.slots[0].device), "hipSetDevice");
+    if (!c.resolved) hip_check(hipMalloc(reinterpret_cast<void**>(&c.resolved), cap), "hipMalloc image");
+    if (want_staging && !c.staging) hip_check(hipMalloc(reinterpret_cast<void**>(&c.staging), cap), "hipMalloc staging");
+    c.capacity = cap;
+}
+
+// One device's part of a pt_render_multi call.
+struct Lane {
+    PtScene* scene = nullptr;
     PtRenderTask task{};
     PtRenderOpts opts{};
     bool active = false;
@@ -1032,33 +1098,15 @@ void render_multi(PtScene** scenes, int n, const PtRenderTask* task, const PtRen
     for (int i = 0; i < n; i++)
         if (!scenes[i]) throw Error(PT_ERR_INVALID_ARGUMENT, "null scene");
     (void)make_camera(task->camera);
+    // work_group.rs:67-69 scales by 1 / iterations: without a sample there is no image to scale
+    if (task->iterations == 0) throw Error(PT_ERR_INVALID_ARGUMENT, "pt_render_multi needs at least one iteration");
     PtRenderOpts base;
     memset(&base, 0, sizeof(base));
     if (opts_in) base = *opts_in;
+    if (mode == PT_SHARD_ROWS && (base.tile_w != 0 || base.tile_h != 0))
+        throw Error(PT_ERR_INVALID_ARGUMENT, "pt_render_multi: a tile cannot be combined with row bands (the bands are the tiles)");
     const size_t floats = (size_t)task->camera.resolution_x * task->camera.resolution_y * 3;
     const size_t bytes = floats * sizeof(float);
-    const auto t_start = std::chrono::steady_clock::now();
-    std::vector<Lane> lanes((size_t)n);
-    float *staging = nullptr, *resolved = nullptr;
-    struct Cleanup {
-        std::vector<Lane>& lanes;
-        float*& staging;
-        float*& resolved;
-        ~Cleanup() {
-            for (Lane& l : lanes) {
-                if (!l.scene) continue;
-                (void)hipSetDevice(l.scene->device);
-                if (l.stream) {
-                    (void)hipStreamSynchronize(l.stream);
-                    (void)hipStreamDestroy(l.stream);
-                }
-                if (l.accum) (void)hipFree(l.accum);
-            }
-            if (!lanes.empty() && lanes[0].scene) (void)hipSetDevice(lanes[0].scene->device);
-            if (staging) (void)hipFree(staging);
-            if (resolved) (void)hipFree(resolved);
-        }
-    } cleanup{lanes, staging, resolved};
     int prev_device = 0;
     hip_check(hipGetDevice(&prev_device), "hipGetDevice");
     struct Restore {
@@ -1066,24 +1114,62 @@ void render_multi(PtScene** scenes, int n, const PtRenderTask* task, const PtRen
         ~Restore() { (void)hipSetDevice(dev); }
     } restore{prev_device};
 
+    std::vector<int> devices;
+    bool distinct = true;
+    for (int i = 0; i < n; i++) {
+        for (int d : devices) distinct = distinct && d != scenes[i]->device;
+        devices.push_back(scenes[i]->device);
+    }
+    const char* how = getenv("PATHTRACING_AMD_REDUCE");
+    const bool want_p2p = how && strcmp(how, "p2p") == 0;
+    const bool use_rccl = n > 1 && distinct && !want_p2p && rccl().ok;
+
+    // set-up, outside the time reported: cached buffers and streams, and the communicators on their first use
+    MultiContext& ctx = multi_context(devices);
+    std::lock_guard<std::mutex> turn(ctx.mu);
+    prepare_multi(ctx, bytes, n > 1 && !use_rccl);
+    if (use_rccl && ctx.comms.empty()) {
+        std::vector<ncclComm_t> comms(devices.size());
+        rccl().check(rccl().comm_init_all(comms.data(), (int)devices.size(), devices.data()), "ncclCommInitAll");
+        ctx.comms = comms; // kept for the life of the process: setting one up takes seconds
+    }
+    // where the image goes: host memory, or memory of the first device (then no copy is made)
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof(attr));
+    const bool out_on_device = hipPointerGetAttributes(&attr, out_rgb) == hipSuccess && attr.type == hipMemoryTypeDevice;
+    if (!out_on_device) (void)hipGetLastError(); // an unregistered host pointer is reported as an error: not one here
+    if (out_on_device && attr.device != devices[0])
+        throw Error(PT_ERR_INVALID_ARGUMENT, "pt_render_multi: a device image buffer must live on the first scene's device");
+
+    const auto t_start = std::chrono::steady_clock::now();
+    std::vector<Lane> lanes((size_t)n);
+    // whatever happens below, nothing may still be running on the shared buffers when the turn ends
+    struct Drain {
+        MultiContext& c;
+        ~Drain() {
+            for (MultiSlot& s : c.slots) {
+                (void)hipSetDevice(s.device);
+                (void)hipStreamSynchronize(s.stream);
+            }
+        }
+    } drain{ctx};
     for (int i = 0; i < n; i++) {
         Lane& l = lanes[(size_t)i];
         l.scene = scenes[i];
         l.active = shard(*task, base, mode, (uint32_t)n, (uint32_t)i, &l.task, &l.opts);
         hip_check(hipSetDevice(l.scene->device), "hipSetDevice");
-        hip_check(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking), "hipStreamCreate");
-        hip_check(hipMalloc(reinterpret_cast<void**>(&l.accum), bytes ? bytes : 16), "hipMalloc accumulation buffer");
-        hip_check(hipMemsetAsync(l.accum, 0, bytes, l.stream), "hipMemsetAsync");
+        hip_check(hipMemsetAsync(ctx.slots[(size_t)i].accum, 0, bytes, ctx.slots[(size_t)i].stream), "hipMemsetAsync");
     }
     // every device renders its share; one host thread per device keeps them all busy
     std::vector<std::thread> threads;
     for (int i = 0; i < n; i++) {
         Lane* l = &lanes[(size_t)i];
+        MultiSlot* s = &ctx.slots[(size_t)i];
         if (!l->active) continue;
-        threads.emplace_back([l] {
+        threads.emplace_back([l, s] {
             l->status = guarded([&] {
                 hip_check(hipSetDevice(l->scene->device), "hipSetDevice");
-                render_accumulate(l->scene, &l->task, &l->opts, l->accum, l->stream, &l->stats);
+                render_accumulate(l->scene, &l->task, &l->opts, s->accum, s->stream, &l->stats);
             });
             if (l->status != PT_OK) l->message = pt::last_error_string();
         });
@@ -1091,58 +1177,51 @@ void render_multi(PtScene** scenes, int n, const PtRenderTask* task, const PtRen
     for (std::thread& t : threads) t.join();
     for (const Lane& l : lanes)
         if (l.status != PT_OK) throw Error(l.status, l.message);
-    for (Lane& l : lanes) { // lanes without a share have only their memset queued
-        hip_check(hipSetDevice(l.scene->device), "hipSetDevice");
-        hip_check(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
+    for (MultiSlot& s : ctx.slots) { // lanes without a share have only their memset queued
+        hip_check(hipSetDevice(s.device), "hipSetDevice");
+        hip_check(hipStreamSynchronize(s.stream), "hipStreamSynchronize");
     }
 
     // the sum of the un-normalised buffers onto the first device (client/src/frame.rs:60-71 does it on the host)
-    Lane& root = lanes[0];
+    MultiSlot& root = ctx.slots[0];
+    const auto t_reduce = std::chrono::steady_clock::now();
     if (n > 1) {
-        std::vector<int> devices;
-        bool distinct = true;
-        for (const Lane& l : lanes) {
-            for (int d : devices) distinct = distinct && d != l.scene->device;
-            devices.push_back(l.scene->device);
-        }
-        const char* how = getenv("PATHTRACING_AMD_REDUCE");
-        const bool want_p2p = how && strcmp(how, "p2p") == 0;
-        if (distinct && !want_p2p && rccl().ok) {
+        if (use_rccl) {
             // RCCL over xGMI: one grouped ncclReduce(sum) with root 0, each rank on its own stream
-            std::vector<ncclComm_t>& comms = communicators(devices);
             rccl().check(rccl().group_start(), "ncclGroupStart");
             for (int i = 0; i < n; i++) {
-                hip_check(hipSetDevice(lanes[(size_t)i].scene->device), "hipSetDevice");
-                rccl().check(rccl().reduce(lanes[(size_t)i].accum, root.accum, floats, ncclFloat, ncclSum, 0, comms[(size_t)i],
-                                           lanes[(size_t)i].stream),
+                MultiSlot& s = ctx.slots[(size_t)i];
+                hip_check(hipSetDevice(s.device), "hipSetDevice");
+                rccl().check(rccl().reduce(s.accum, root.accum, floats, ncclFloat, ncclSum, 0, ctx.comms[(size_t)i], s.stream),
                              "ncclReduce");
             }
             rccl().check(rccl().group_end(), "ncclGroupEnd");
-            for (Lane& l : lanes) {
-                hip_check(hipSetDevice(l.scene->device), "hipSetDevice");
-                hip_check(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
+            for (MultiSlot& s : ctx.slots) {
+                hip_check(hipSetDevice(s.device), "hipSetDevice");
+                hip_check(hipStreamSynchronize(s.stream), "hipStreamSynchronize");
             }
         } else {
             // peer copies: every other buffer is copied to the first device and added there, in device order
             // (also the route for several scenes on one device, which RCCL does not take)
-            hip_check(hipSetDevice(root.scene->device), "hipSetDevice");
-            hip_check(hipMalloc(reinterpret_cast<void**>(&staging), bytes ? bytes : 16), "hipMalloc staging");
+            hip_check(hipSetDevice(root.device), "hipSetDevice");
             for (int i = 1; i < n; i++) {
-                hip_check(hipMemcpyPeerAsync(staging, root.scene->device, lanes[(size_t)i].accum, lanes[(size_t)i].scene->device,
-                                             bytes, root.stream),
+                hip_check(hipMemcpyPeerAsync(ctx.staging, root.device, ctx.slots[(size_t)i].accum, ctx.slots[(size_t)i].device, bytes,
+                                             root.stream),
                           "hipMemcpyPeerAsync");
-                hip_check(ptk::frame_add(root.accum, staging, floats, root.stream), "frame_add");
+                hip_check(ptk::frame_add(root.accum, ctx.staging, floats, root.stream), "frame_add");
             }
+            hip_check(hipStreamSynchronize(root.stream), "hipStreamSynchronize");
         }
     }
-    hip_check(hipSetDevice(root.scene->device), "hipSetDevice");
-    hip_check(hipMalloc(reinterpret_cast<void**>(&resolved), bytes ? bytes : 16), "hipMalloc image");
+    const double reduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_reduce).count();
+    hip_check(hipSetDevice(root.device), "hipSetDevice");
     // get_image: work_group.rs:67-69 scale, cpu_renderer/mod.rs:143-175 flip
     const float scale = 1.0f / (float)task->iterations;
-    hip_check(ptk::resolve_image(root.accum, (uint32_t)task->camera.resolution_x, (uint32_t)task->camera.resolution_y, scale,
-                                 resolved, root.stream),
+    float* image = out_on_device ? out_rgb : ctx.resolved;
+    hip_check(ptk::resolve_image(root.accum, (uint32_t)task->camera.resolution_x, (uint32_t)task->camera.resolution_y, scale, image,
+                                 root.stream),
               "resolve_image");
-    hip_check(hipMemcpyAsync(out_rgb, resolved, bytes, hipMemcpyDeviceToHost, root.stream), "hipMemcpy D2H");
+    if (!out_on_device) hip_check(hipMemcpyAsync(out_rgb, ctx.resolved, bytes, hipMemcpyDeviceToHost, root.stream), "hipMemcpy D2H");
     hip_check(hipStreamSynchronize(root.stream), "hipStreamSynchronize");
     if (stats) {
         memset(stats, 0, sizeof(*stats));
@@ -1151,10 +1230,19 @@ void render_multi(PtScene** scenes, int n, const PtRenderTask* task, const PtRen
             stats->rays += l.stats.rays;
             stats->paths += l.stats.paths;
             stats->searches += l.stats.searches;
+            stats->node_visits += l.stats.node_visits;
+            stats->triangle_tests += l.stats.triangle_tests;
+            stats->wave_node_steps += l.stats.wave_node_steps;
+            stats->wave_leaf_steps += l.stats.wave_leaf_steps;
+            stats->wave_leaf_rounds += l.stats.wave_leaf_rounds;
+            stats->search_kernel_ms += l.stats.search_kernel_ms;
+            stats->search_kernel_launches += l.stats.search_kernel_launches;
             stats->bvh_bytes = l.stats.bvh_bytes;
         }
-        // the whole call on the host's clock: renders side by side, the reduce, the resolve and the copy back
+        // the call on the host's clock once its buffers, streams and communicators exist: renders side by side,
+        // the reduce, the resolve and the copy back
         stats->render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+        stats->reduce_ms = reduce_ms;
     }
 }
 
@@ -1346,6 +1434,9 @@ PtStatus pt_device_release_workspace(int device) {
         hip_check(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
         if (device < 0 || device >= ndev) throw Error(PT_ERR_DEVICE, "no such HIP device");
         DeviceGuard guard(device);
+        // first what pt_render_multi keeps on this device between calls (a call in progress holds its
+        // context's lock and takes the device's below it: the same order here)
+        release_multi_buffers(device);
         DeviceState& ds = device_state(device);
         std::lock_guard<std::mutex> lock(ds.mu);
         for (int k = 0; k < kMaxInFlight; k++) {
@@ -1483,18 +1574,17 @@ PtStatus pt_worker_handle_message(PtWorker* worker, const char* task_json, const
         } catch (const std::exception& e) {
             throw Error(PT_ERR_PARSE, std::string("Failed to decode render task: ") + e.what());
         }
+        // the wire form is RenderTask (render_task.rs:23-29): serde refuses a frame without scene_md5, main.rs:79
+        if (scene_md5.empty()) throw Error(PT_ERR_PARSE, "Failed to decode render task: missing field `scene_md5`");
+        for (char c : scene_md5)
+            if (!((c >= '0' && c <= '9') || (c >= 'a' && c <= 'f') || (c >= 'A' && c <= 'F')))
+                throw Error(PT_ERR_INVALID_ARGUMENT, "scene_md5 is not a hex digest");
         // ... Worker::render, lib.rs:31-48: the scene from the cache, or loaded from its bucket
-        const std::string key = scene_md5.empty() ? "path:" + scene_path : scene_md5;
+        const std::string key = scene_md5;
         auto it = worker->cached_scenes.find(key);
         if (it == worker->cached_scenes.end()) {
-            std::string root = worker->store_root;
-            if (!scene_md5.empty()) {
-                for (char c : scene_md5)
-                    if (!((c >= '0' && c <= '9') || (c >= 'a' && c <= 'f') || (c >= 'A' && c <= 'F')))
-                        throw Error(PT_ERR_INVALID_ARGUMENT, "scene_md5 is not a hex digest");
-                root += "/" + scene_md5;
-            }
-            pt::FileStore store(root);
+            // the names in the frame and in the files it leads to are a peer's: they stay inside the bucket
+            pt::FileStore store(worker->store_root + "/" + scene_md5, /*confined=*/true);
             PtWorker::Entry entry;
             entry.host = pt::load_scene(store, scene_path);
             try {

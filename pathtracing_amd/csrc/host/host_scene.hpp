@@ -35,14 +35,18 @@ struct HostImage {
 // file_store.rs:27-35 (`fetch_file`) against a local directory.
 class FileStore {
 public:
-    explicit FileStore(std::string root_dir) : root_(std::move(root_dir)) {}
+    // `confined`: names come from an untrusted peer (a task frame, and the files it names); a name that is
+    // absolute or has a ".." component is refused (PT_ERR_INVALID_ARGUMENT) instead of leaving the directory.
+    explicit FileStore(std::string root_dir, bool confined = false) : root_(std::move(root_dir)), confined_(confined) {}
     std::vector<uint8_t> fetch_file(const std::string& path) const;
     bool exists(const std::string& path) const;
     // Replaces (or creates) the file: written beside it under a temporary name, then renamed over it.
     void write_file(const std::string& path, const std::vector<uint8_t>& data) const;
 
 private:
+    std::string full_path(const std::string& path) const;
     std::string root_;
+    bool confined_ = false;
 };
 
 struct HostScene {

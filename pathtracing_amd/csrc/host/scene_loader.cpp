@@ -29,15 +29,29 @@ static std::string join_path(const std::string& root, const std::string& path) {
     return root + "/" + path;
 }
 
+std::string FileStore::full_path(const std::string& path) const {
+    if (confined_) {
+        bool escapes = path.empty() || path[0] == '/' || path[0] == '\\' || path.find('\0') != std::string::npos;
+        for (size_t i = 0; i < path.size() && !escapes;) { // component by component
+            size_t j = path.find_first_of("/\\", i);
+            if (j == std::string::npos) j = path.size();
+            if (path.compare(i, j - i, "..") == 0) escapes = true;
+            i = j + 1;
+        }
+        if (escapes) throw Error(PT_ERR_INVALID_ARGUMENT, "file name '" + path + "' leaves the scene's bucket");
+    }
+    return join_path(root_, path);
+}
+
 bool FileStore::exists(const std::string& path) const {
-    FILE* f = fopen(join_path(root_, path).c_str(), "rb");
+    FILE* f = fopen(full_path(path).c_str(), "rb");
     if (!f) return false;
     fclose(f);
     return true;
 }
 
 std::vector<uint8_t> FileStore::fetch_file(const std::string& path) const {
-    std::string full = join_path(root_, path);
+    std::string full = full_path(path);
     FILE* f = fopen(full.c_str(), "rb");
     if (!f) throw Error(PT_ERR_IO, "cannot open '" + full + "'");
     std::vector<uint8_t> out;
@@ -51,7 +65,7 @@ std::vector<uint8_t> FileStore::fetch_file(const std::string& path) const {
 }
 
 void FileStore::write_file(const std::string& path, const std::vector<uint8_t>& data) const {
-    std::string full = join_path(root_, path);
+    std::string full = full_path(path);
     std::string tmp = full + ".tmp" + std::to_string((long long)getpid());
     FILE* f = fopen(tmp.c_str(), "wb");
     if (!f) throw Error(PT_ERR_IO, "cannot create '" + tmp + "'");

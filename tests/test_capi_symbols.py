@@ -22,7 +22,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     raw = C.CDLL(N.LIB_PATH)
     for name in declared:
         assert getattr(raw, name) is not None
-    assert N.lib.pt_abi_version() == 2
+    assert N.lib.pt_abi_version() == 3
 
 
 def test_struct_layouts_match_the_header(tmp_path):

@@ -103,12 +103,50 @@ def test_connection_loop_round_over_md5_buckets(tmp_path):
     with pytest.raises(N.PathTracingError) as e:
         worker.handle_message(json.dumps(wire))
     assert e.value.status == 3
-    # the file form (no scene_md5) reads the store's root
-    shutil.copy(os.path.join(H.SCENE_DATA, "scene0.json"), os.path.join(store, "scene0.json"))
-    shutil.copytree(os.path.join(H.SCENE_DATA, "materials"), os.path.join(store, "materials"))
-    shutil.copy(os.path.join(H.SCENE_DATA, "test_texture_0.png"), os.path.join(store, "test_texture_0.png"))
+    # the file form (no scene_md5) is not a RenderTask: serde refuses it upstream (render_task.rs:23-29, main.rs:79)
     del wire["scene_md5"]
-    wire["scene"] = "./scene0.json"
-    out = worker.handle_message(json.dumps(wire))
-    assert worker.cached_scene_count == 2 and len(out) == 8 + 80 * 56 * 12
+    with pytest.raises(N.PathTracingError) as e:
+        worker.handle_message(json.dumps(wire))
+    assert e.value.status == 4 and "Failed to decode render task" in e.value.message and "scene_md5" in e.value.message
+    worker.close()
+
+
+@pytest.mark.gpu
+def test_names_in_a_frame_stay_inside_the_bucket(tmp_path):
+    """The scene name of a task frame, and the names inside the files it leads to, come from a peer:
+    none of them may read or write outside store/<scene_md5>/."""
+    store = str(tmp_path / "store")
+    md5 = "ab" * 16
+    bucket = os.path.join(store, md5)
+    shutil.copytree(H.SCENE_DATA, bucket)
+    outside = tmp_path / "outside"
+    shutil.copytree(H.SCENE_DATA, outside)
+    with open(os.path.join(H.SCENE_DATA, "render_task.json")) as f:
+        wire = json.load(f)
+    wire["scene_md5"] = md5
+    wire["camera"]["resolution"] = [32, 24]
+    wire["config"] = {"trace_depth": 2, "iterations": 1}
+    worker = F.WorkerFrontEnd(store, 0)
+    for name in ("../../outside/scene.json", "/etc/passwd", "./a/../../x.json", "..", str(outside / "scene.json")):
+        wire["scene"] = name
+        with pytest.raises(N.PathTracingError) as e:
+            worker.handle_message(json.dumps(wire))
+        assert e.value.status == 1 and "leaves the scene's bucket" in e.value.message, name
+    # a scene file inside the bucket whose kd_tree and mesh names point outside it
+    with open(os.path.join(bucket, "scene.json")) as f:
+        text = f.read()
+    assert "./cube.tree" in text and "./cube.obj" in text
+    with open(os.path.join(bucket, "tree_outside.json"), "w") as f:
+        f.write(text.replace("./cube.tree", "../../outside/written.tree"))
+    with open(os.path.join(bucket, "mesh_outside.json"), "w") as f:
+        f.write(text.replace("./cube.obj", "../../outside/cube.obj"))
+    for name in ("./tree_outside.json", "./mesh_outside.json"):
+        wire["scene"] = name
+        with pytest.raises(N.PathTracingError) as e:
+            worker.handle_message(json.dumps(wire))
+        assert e.value.status == 1, name
+    assert not os.path.exists(outside / "written.tree") and worker.cached_scene_count == 0
+    # names with dots that stay inside are fine
+    wire["scene"] = "./scene.json"
+    assert len(worker.handle_message(json.dumps(wire))) == 8 + 32 * 24 * 12
     worker.close()
