@@ -314,3 +314,26 @@ def last_error() -> str:
 def check(status: int) -> None:
     if status != PT_OK:
         raise PathTracingError(status, last_error())
+
+
+def kernel_fingerprint(path: str = LIB_PATH) -> str:
+    """First 16 hex digits of the SHA-256 of the library's device code (its ``.hip_fatbin``
+    section): equal for two builds exactly when the kernels are the same machine code,
+    whatever the host code around them.  Recorded beside counter measurements, so that a
+    reader can tell whether they belong to the kernels it has loaded."""
+    import hashlib
+    import struct
+
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"\x7fELF" or data[4] != 2:
+        raise ValueError(f"{path} is not a 64-bit ELF file")
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+    sections = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
+    names = sections[shstrndx]
+    for name_off, _type, _flags, _addr, offset, size, *_ in sections:
+        end = data.index(b"\0", names[4] + name_off)
+        if data[names[4] + name_off:end] == b".hip_fatbin":
+            return hashlib.sha256(data[offset:offset + size]).hexdigest()[:16]
+    raise ValueError(f"{path} has no .hip_fatbin section")

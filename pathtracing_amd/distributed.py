@@ -71,12 +71,14 @@ def shard_opts(task: RenderTask, world: int, rank: int, mode: str, seed: int = 0
 
 
 def render_sharded(render_accumulate: Callable[[RenderTask, RenderOpts, "object"], None], task: RenderTask,
-                   accum, mode: str = "samples", seed: int = 0, group=None, stage_on_host: bool = False):
+                   accum, mode: str = "samples", seed: int = 0, group=None, stage_on_host: bool = False,
+                   on_reduce: Optional[Callable[[str], None]] = None):
     """Renders this rank's share into `accum` (a zeroed torch tensor of W*H*3 f32 on
     the rank's device, camera-space layout) and sums all ranks' buffers onto rank 0.
     `render_accumulate(task, opts, accum)` must add the samples it renders into
     `accum`.  Returns `accum` (complete on rank 0 only).  `stage_on_host` sums through
-    a host copy, for process groups whose backend cannot reduce device tensors (gloo)."""
+    a host copy, for process groups whose backend cannot reduce device tensors (gloo).
+    `on_reduce("start")` / `on_reduce("end")` are called around the sum (for timing it)."""
     import torch.distributed as dist
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -85,12 +87,16 @@ def render_sharded(render_accumulate: Callable[[RenderTask, RenderOpts, "object"
     if opts is not None:
         render_accumulate(sub, opts, accum)
     if world > 1:
+        if on_reduce is not None:
+            on_reduce("start")
         if stage_on_host:
             host = accum.cpu()
             dist.reduce(host, dst=0, op=dist.ReduceOp.SUM, group=group)
             accum.copy_(host)
         else:
             dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM, group=group)
+        if on_reduce is not None:
+            on_reduce("end")
     return accum
 
 

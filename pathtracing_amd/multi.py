@@ -30,14 +30,23 @@ def shard(task: RenderTask, opts: Optional[RenderOpts], mode: str, world: int, r
     return (int(ot.iterations) if active.value or mode == "samples" else 0), int(oo.sample_offset), tile
 
 
-def render_multi(renderers: Sequence[HipRenderer], task: RenderTask, opts: Optional[RenderOpts] = None, mode: str = "samples"):
+def render_multi(renderers: Sequence[HipRenderer], task: RenderTask, opts: Optional[RenderOpts] = None, mode: str = "samples",
+                 out_ptr: Optional[int] = None, width_height: Optional[Tuple[int, int]] = None):
     """``Renderer::render`` over the devices the ``renderers`` live on (one scene handle per
-    device).  Returns (image float32 [H, W, 3] top row first, PtRenderStats)."""
+    device).  Returns (image float32 [H, W, 3] top row first, PtRenderStats).  With ``out_ptr``
+    (W*H*3 floats in the memory of the first renderer's device) the image is resolved there,
+    nothing is copied to the host and the first item returned is None."""
     t = task.to_native()
     o = (opts or RenderOpts()).to_native()
     w, h = int(t.camera.resolution_x), int(t.camera.resolution_y)
-    out = np.empty((h, w, 3), dtype=np.float32)
     handles = (C.c_void_p * len(renderers))(*[r._handle for r in renderers])
     stats = N.PtRenderStats()
+    if out_ptr is not None:
+        if width_height is not None and tuple(width_height) != (w, h):
+            raise ValueError("the output buffer was sized for another resolution")
+        N.check(N.lib.pt_render_multi(handles, len(renderers), C.byref(t), C.byref(o), _MODES[mode], C.c_void_p(out_ptr),
+                                      C.byref(stats)))
+        return None, stats
+    out = np.empty((h, w, 3), dtype=np.float32)
     N.check(N.lib.pt_render_multi(handles, len(renderers), C.byref(t), C.byref(o), _MODES[mode], out.ctypes.data, C.byref(stats)))
     return out, stats

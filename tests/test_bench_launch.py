@@ -29,14 +29,41 @@ def _run(*flags, timeout=600):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("config,scaling", [("c3", "weak"), ("c4", "strong"), ("c5", "strong")])
-def test_plain_invocation_starts_its_ranks(config, scaling):
+@pytest.mark.parametrize("config", ["c3", "c4", "c5"])
+def test_plain_invocation_starts_its_ranks(config):
     line = _run("--gpus", "2", "--steps", "2", "--warmup", "1", "--stub-render", "--config", config)
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1
-    assert line["scaling"] == scaling and line["config"]["ranks"] == 2 and len(line["config"]["devices"]) == 2
+    # every configuration renders a fixed frame, cut over the ranks: the frame the metric names, on more GPUs
+    assert line["scaling"] == "strong" and line["config"]["ranks"] == 2 and len(line["config"]["devices"]) == 2
     assert line["config"]["frame_mean"] == 1.0
-    per_step = 64 * 40 * (4 if config == "c3" else 8)  # c3 stand-in: 2 samples per rank; c4, c5: 8 in all
-    assert line["config"]["rays_per_step"] == per_step and line["value"] > 0
+    assert line["config"]["rays_per_step"] == 64 * 40 * 8 and line["value"] > 0  # the stand-in frame: 8 samples in all
+    assert line["config"]["reduce_ms"] >= 0.0
+    if config == "c3":  # ... and beside it the same loop with that many samples on every rank
+        weak = line["extra"]["weak_64spp_per_gpu"]
+        assert weak["scaling"] == "weak" and weak["samples_per_pixel_in_all"] == 16
+        assert weak["rays_per_step"] == 64 * 40 * 16 and weak["frame_mean"] == 1.0 and weak["value"] > 0
+    else:
+        assert "extra" not in line
+
+
+def test_result_line_is_found_among_foreign_output():
+    """The ranks share one pipe with the collective library's banners: whatever else is on it --
+    valid JSON that is no object, half a line -- the parser neither raises nor loses rank 0's line."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_module", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    result = json.dumps({"metric": "Mrays/s dragon 1080p 64spp", "value": 1.0})
+    noise = ["1", "null", "[1]", '"x"', "true", "3.5", '{"metric": "Mr', "[Gloo] Rank 0 is connected to 1 peer ranks. Expected number of connected peer ranks is : ",
+             '{"other": 1}', "", "   "]
+    line, foreign = bench.pick_result_line("\n".join(noise[:5] + [result] + noise[5:]))
+    assert line == result and len(foreign) == len([n for n in noise if n.strip()])
+    assert bench.pick_result_line("\n".join(noise)) == (None, [n for n in noise if n.strip()])
+    assert bench.pick_result_line("") == (None, [])
+    # the last result line wins (a rank that printed twice)
+    second = json.dumps({"metric": "m", "value": 2.0})
+    assert bench.pick_result_line(result + "\n1\n" + second)[0] == second
 
 
 def test_single_rank_stub_line_has_the_contract_fields():
@@ -61,10 +88,29 @@ def test_two_ranks_on_one_gpu_render_the_frame():
     out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "pathtracing_amd_dragon")
     task = H.load_task(synth.write_dragon_scene(out, H.SCENE_DATA))
     task.camera.resolution = [1920, 1080]
-    task.config = P.Config(trace_depth=8, iterations=128)
     gpu = P.HipRenderer.init(P.Scene.load(out, task.scene), 0)
-    img = gpu.render(task, P.RenderOpts(seed=0))
-    assert gpu.last_stats.rays == line["config"]["rays_per_step"]
-    mean = float(np.nanmean(img))
-    assert abs(mean - line["config"]["frame_mean"]) <= 1e-5 * mean
+    for iters, part in ((64, line["config"]), (128, line["extra"]["weak_64spp_per_gpu"])):
+        task.config = P.Config(trace_depth=8, iterations=iters)
+        img = gpu.render(task, P.RenderOpts(seed=0))
+        assert gpu.last_stats.rays == part["rays_per_step"]
+        mean = float(np.nanmean(img))
+        assert abs(mean - part["frame_mean"]) <= 1e-5 * mean
     gpu.close()
+
+
+@pytest.mark.gpu
+def test_one_process_drives_two_scene_handles():
+    """--inproc: the same steps through pt_render_multi (threads, streams, cached buffers, the peer-copy sum:
+    both handles live on GPU 0); rays and frame mean against the two-process rehearsal's, which renders the
+    same frame through torch.distributed."""
+    common = ("--gpus", "2", "--steps", "2", "--warmup", "1", "--rehearse", "--no-cpu-baseline", "--no-hbm-regime")
+    one = _run(*common, "--inproc")
+    assert one["n_gpus"] == 2 and one["config"]["processes"] == 1 and "pt_render_multi" in one["config"]["sharding"]
+    assert one["scaling"] == "strong" and one["config"]["reduce_ms"] > 0.0 and one["roofline"]["frac"] > 0.0
+    two = _run(*common)
+    assert two["config"]["processes"] == 2
+    assert one["config"]["rays_per_step"] == two["config"]["rays_per_step"]
+    assert abs(one["config"]["frame_mean"] - two["config"]["frame_mean"]) <= 1e-5 * two["config"]["frame_mean"]
+    for line in (one, two):
+        weak = line["extra"]["weak_64spp_per_gpu"]
+        assert weak["samples_per_pixel_in_all"] == 128 and weak["rays_per_step"] > 1.9 * line["config"]["rays_per_step"]
