@@ -598,7 +598,7 @@ void build_mesh(PtScene& s, const PtMeshDesc& m, const PtTreeBlob* blob, ptk::DM
     }
     if (!adopted) {
         auto t0 = std::chrono::steady_clock::now();
-        bvh = pt::build_bvh(m.positions, n, 4); // leaves of 2..4 triangles render equally fast, 1 and 6+ slower
+        bvh = pt::build_bvh(m.positions, n, pt::default_bvh_tuning().max_leaf);
         wide = pt::widen_bvh(bvh);
         s.info.build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (wide.max_stack > ptk::traversal_stack_capacity())
@@ -907,7 +907,7 @@ uint32_t cache_trees(pt::HostScene& hs, const pt::FileStore& store) {
         if (!hs.trees[t].empty() &&
             pt::deserialize_tree(hs.trees[t].data(), hs.trees[t].size(), mesh.positions.data(), mesh.triangle_count, &bvh))
             continue; // a hit: nothing to write
-        bvh = pt::build_bvh(mesh.positions.data(), mesh.triangle_count, 4);
+        bvh = pt::build_bvh(mesh.positions.data(), mesh.triangle_count, pt::default_bvh_tuning().max_leaf);
         std::vector<uint8_t> blob = pt::serialize_tree(bvh, mesh.positions.data(), mesh.triangle_count);
         store.write_file(hs.tree_paths[t], blob);
         hs.trees[t] = std::move(blob);
@@ -1837,7 +1837,7 @@ PtStatus pt_tree_build(const PtMeshDesc* mesh, uint8_t** out_data, uint64_t* out
     return guarded([&] {
         if (!mesh || !out_data || !out_size || (mesh->triangle_count && !mesh->positions))
             throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
-        pt::BuiltBvh bvh = pt::build_bvh(mesh->positions, mesh->triangle_count, 4);
+        pt::BuiltBvh bvh = pt::build_bvh(mesh->positions, mesh->triangle_count, pt::default_bvh_tuning().max_leaf);
         std::vector<uint8_t> blob = pt::serialize_tree(bvh, mesh->positions, mesh->triangle_count);
         uint8_t* p = static_cast<uint8_t*>(malloc(blob.size() ? blob.size() : 1));
         if (!p) throw std::bad_alloc();

@@ -2,16 +2,19 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <future>
 #include <limits>
+#include <memory>
 
 namespace pt {
 namespace {
 
 constexpr float kInf = std::numeric_limits<float>::infinity();
-constexpr int kBins = 16;
+constexpr int kMaxBins = 64;
+constexpr uint32_t kMaxSweep = 256;
 constexpr int kSahDepthLimit = 30; // below this depth only balanced median splits
 
 struct Ref {
@@ -41,61 +44,105 @@ struct SubTree {
 
 struct Builder {
     std::vector<Ref>& refs;
-    uint32_t max_leaf;
+    uint32_t max_leaf; // ranges up to this size become leaves without a split
+    int bins;
+    uint32_t sweep_below;
+
+    // Every split position of refs[lo, hi) sorted by centroid, per axis; leaves the range sorted along
+    // the winning axis and returns the split position (0 = no axis has any extent).
+    size_t sweep_split(size_t lo, size_t hi) {
+        const size_t n = hi - lo;
+        float right_area[kMaxSweep];
+        int best_axis = -1;
+        size_t best_at = 0;
+        float best_cost = kInf;
+        int sorted_axis = -1;
+        auto sort_axis = [&](int a) {
+            std::sort(refs.begin() + lo, refs.begin() + hi, [a](const Ref& p, const Ref& q) {
+                return p.c[a] < q.c[a] || (p.c[a] == q.c[a] && p.idx < q.idx);
+            });
+            sorted_axis = a;
+        };
+        for (int a = 0; a < 3; a++) {
+            sort_axis(a);
+            if (!(refs[hi - 1].c[a] > refs[lo].c[a])) continue;
+            Box acc;
+            for (size_t i = n - 1; i >= 1; i--) {
+                acc.grow(refs[lo + i].bmin, refs[lo + i].bmax);
+                right_area[i] = acc.half_area();
+            }
+            acc = Box();
+            for (size_t i = 1; i < n; i++) {
+                acc.grow(refs[lo + i - 1].bmin, refs[lo + i - 1].bmax);
+                float cost = acc.half_area() * (float)i + right_area[i] * (float)(n - i);
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = a;
+                    best_at = i;
+                }
+            }
+        }
+        if (best_axis < 0) return 0;
+        if (sorted_axis != best_axis) sort_axis(best_axis);
+        return lo + best_at;
+    }
+
+    size_t binned_split(size_t lo, size_t hi, const Box& cb) {
+        int best_axis = -1, best_bin = -1;
+        float best_cost = kInf;
+        for (int a = 0; a < 3; a++) {
+            float ext = cb.mx[a] - cb.mn[a];
+            if (!(ext > 0.0f)) continue;
+            Box bin[kMaxBins];
+            uint32_t cnt[kMaxBins] = {0};
+            float scale = (float)bins / ext;
+            for (size_t i = lo; i < hi; i++) {
+                int b = std::min(bins - 1, std::max(0, (int)((refs[i].c[a] - cb.mn[a]) * scale)));
+                cnt[b]++;
+                bin[b].grow(refs[i].bmin, refs[i].bmax);
+            }
+            float right_area[kMaxBins];
+            uint32_t right_cnt[kMaxBins];
+            Box acc;
+            uint32_t c = 0;
+            for (int b = bins - 1; b >= 1; b--) {
+                if (cnt[b]) acc.grow(bin[b].mn, bin[b].mx);
+                c += cnt[b];
+                right_area[b] = c ? acc.half_area() : 0.0f;
+                right_cnt[b] = c;
+            }
+            acc = Box();
+            c = 0;
+            for (int b = 0; b < bins - 1; b++) {
+                if (cnt[b]) acc.grow(bin[b].mn, bin[b].mx);
+                c += cnt[b];
+                if (c == 0 || right_cnt[b + 1] == 0) continue;
+                float cost = acc.half_area() * (float)c + right_area[b + 1] * (float)right_cnt[b + 1];
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = a;
+                    best_bin = b;
+                }
+            }
+        }
+        if (best_axis < 0) return 0;
+        float ext = cb.mx[best_axis] - cb.mn[best_axis];
+        float scale = (float)bins / ext, base = cb.mn[best_axis];
+        int a = best_axis, sb = best_bin, nb = bins;
+        auto it = std::partition(refs.begin() + lo, refs.begin() + hi, [=](const Ref& r) {
+            int b = std::min(nb - 1, std::max(0, (int)((r.c[a] - base) * scale)));
+            return b <= sb;
+        });
+        return (size_t)(it - refs.begin());
+    }
 
     // Chooses where to split refs[lo, hi); returns the split position.
     size_t split(size_t lo, size_t hi, int depth) {
         size_t n = hi - lo;
         Box cb;
         for (size_t i = lo; i < hi; i++) cb.grow(refs[i].c, refs[i].c);
-        int best_axis = -1, best_bin = -1;
-        float best_cost = kInf;
         if (depth < kSahDepthLimit) {
-            for (int a = 0; a < 3; a++) {
-                float ext = cb.mx[a] - cb.mn[a];
-                if (!(ext > 0.0f)) continue;
-                Box bins[kBins];
-                uint32_t cnt[kBins] = {0};
-                float scale = (float)kBins / ext;
-                for (size_t i = lo; i < hi; i++) {
-                    int b = std::min(kBins - 1, std::max(0, (int)((refs[i].c[a] - cb.mn[a]) * scale)));
-                    cnt[b]++;
-                    bins[b].grow(refs[i].bmin, refs[i].bmax);
-                }
-                float right_area[kBins];
-                uint32_t right_cnt[kBins];
-                Box acc;
-                uint32_t c = 0;
-                for (int b = kBins - 1; b >= 1; b--) {
-                    if (cnt[b]) acc.grow(bins[b].mn, bins[b].mx);
-                    c += cnt[b];
-                    right_area[b] = c ? acc.half_area() : 0.0f;
-                    right_cnt[b] = c;
-                }
-                acc = Box();
-                c = 0;
-                for (int b = 0; b < kBins - 1; b++) {
-                    if (cnt[b]) acc.grow(bins[b].mn, bins[b].mx);
-                    c += cnt[b];
-                    if (c == 0 || right_cnt[b + 1] == 0) continue;
-                    float cost = acc.half_area() * (float)c + right_area[b + 1] * (float)right_cnt[b + 1];
-                    if (cost < best_cost) {
-                        best_cost = cost;
-                        best_axis = a;
-                        best_bin = b;
-                    }
-                }
-            }
-        }
-        if (best_axis >= 0) {
-            float ext = cb.mx[best_axis] - cb.mn[best_axis];
-            float scale = (float)kBins / ext, base = cb.mn[best_axis];
-            int a = best_axis, sb = best_bin;
-            auto it = std::partition(refs.begin() + lo, refs.begin() + hi, [=](const Ref& r) {
-                int b = std::min(kBins - 1, std::max(0, (int)((r.c[a] - base) * scale)));
-                return b <= sb;
-            });
-            size_t mid = (size_t)(it - refs.begin());
+            size_t mid = n <= sweep_below ? sweep_split(lo, hi) : binned_split(lo, hi, cb);
             if (mid > lo && mid < hi) return mid;
         }
         // balanced split on the widest centroid axis (ties broken by index: deterministic)
@@ -145,6 +192,274 @@ struct Builder {
     }
 };
 
+inline uint32_t leaf_first(int32_t ref) { return (uint32_t)(~ref) >> 3; }
+inline uint32_t leaf_count(int32_t ref) { return ((uint32_t)(~ref) & 7u) + 1u; }
+
+inline float half_area(const float* mn, const float* mx) {
+    float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// Which descendants of every binary node make the cheapest four-wide tree, and which subtrees are cheaper as
+// one leaf.  The expected cost of a search is taken as the sum over the wide nodes it would visit of their
+// surface area (1 per visit) plus, over the leaves, area x triangles x tri_cost.  With cost(n, i) the smallest
+// cost of node n's subtree when it may take up to i child slots of the wide node above it:
+//   cost(n, 1) = min(area(n) * triangles(n) * tri_cost                       [n becomes a leaf, if small enough]
+//                    area(n) + min_j cost(left, j) + cost(right, 4 - j))     [n becomes a wide node]
+//   cost(n, i) = min(cost(n, i - 1), min_j cost(left, j) + cost(right, i - j))   [n dissolves into the node above]
+// Nodes are in pre-order, so one pass from the last node to the first sees children before parents.
+struct WidePlan {
+    std::vector<float> cost;     // [3 * node + i - 1]
+    std::vector<uint8_t> choice; // same index: 0 = leaf (i = 1) / as with i - 1 slots (i > 1); j = the left child takes j slots
+    std::vector<float> area;
+    std::vector<uint32_t> triangles;
+
+    WidePlan(const std::vector<ptk::BvhNode>& nodes, uint32_t max_leaf, float tri_cost) {
+        const size_t n = nodes.size();
+        cost.resize(3 * n);
+        choice.resize(3 * n);
+        area.resize(n);
+        triangles.resize(n);
+        for (size_t k = n; k-- > 0;) {
+            const ptk::BvhNode& nd = nodes[k];
+            float cl[3], cr[3];
+            uint32_t pl, pr;
+            side(nd.left, nd.lmin, nd.lmax, tri_cost, cl, &pl);
+            side(nd.right, nd.rmin, nd.rmax, tri_cost, cr, &pr);
+            Box b;
+            b.grow(nd.lmin, nd.lmax);
+            b.grow(nd.rmin, nd.rmax);
+            area[k] = b.half_area();
+            triangles[k] = pl + pr;
+            float spread[5];
+            uint8_t at[5];
+            for (int slots = 2; slots <= 4; slots++) {
+                spread[slots] = kInf;
+                at[slots] = 1;
+                for (int j = 1; j < slots; j++) {
+                    if (j > 3 || slots - j > 3) continue;
+                    float c = cl[j - 1] + cr[slots - j - 1];
+                    if (c < spread[slots]) {
+                        spread[slots] = c;
+                        at[slots] = (uint8_t)j;
+                    }
+                }
+            }
+            float as_node = area[k] + spread[4];
+            float as_leaf = triangles[k] <= max_leaf ? area[k] * (float)triangles[k] * tri_cost : kInf;
+            float* c = &cost[3 * k];
+            uint8_t* ch = &choice[3 * k];
+            if (as_leaf <= as_node) {
+                c[0] = as_leaf;
+                ch[0] = 0;
+            } else {
+                c[0] = as_node;
+                ch[0] = at[4];
+            }
+            for (int i = 2; i <= 3; i++) {
+                if (spread[i] < c[i - 2]) {
+                    c[i - 1] = spread[i];
+                    ch[i - 1] = at[i];
+                } else {
+                    c[i - 1] = c[i - 2];
+                    ch[i - 1] = 0;
+                }
+            }
+        }
+    }
+
+    void side(int32_t ref, const float* mn, const float* mx, float tri_cost, float* c, uint32_t* tris) const {
+        if (ref < 0) {
+            *tris = leaf_count(ref);
+            c[0] = c[1] = c[2] = half_area(mn, mx) * (float)*tris * tri_cost;
+        } else {
+            *tris = triangles[(size_t)ref];
+            memcpy(c, &cost[3 * (size_t)ref], 3 * sizeof(float));
+        }
+    }
+};
+
+// Rounds of tree rotations over a binary tree whose leaves hold one triangle each: at every node, the exchange
+// of a child with a grandchild on the other side that shrinks the surface area of the child in between the
+// most is made, children before parents (only that one box changes, so the gain is exact).  The tree is then
+// laid out again in depth-first order, which keeps a subtree's triangles adjacent in `order`.
+void rotate_tree(SubTree& tree, int32_t* root_ref, uint32_t rounds) {
+    const size_t inner = tree.nodes.size();
+    if (*root_ref < 0 || inner < 2 || rounds == 0) return;
+    // nodes [0, inner) are the inner nodes, inner + k is the leaf of order[k]
+    const size_t total = inner + tree.order.size();
+    struct Node {
+        float mn[3], mx[3];
+        int32_t l, r; // < 0: none (leaf)
+    };
+    std::vector<Node> nd(total);
+    auto index_of = [&](int32_t ref) { return ref >= 0 ? (size_t)ref : inner + leaf_first(ref); };
+    for (size_t k = inner; k-- > 0;) {
+        const ptk::BvhNode& b = tree.nodes[k];
+        size_t l = index_of(b.left), r = index_of(b.right);
+        memcpy(nd[l].mn, b.lmin, 12);
+        memcpy(nd[l].mx, b.lmax, 12);
+        memcpy(nd[r].mn, b.rmin, 12);
+        memcpy(nd[r].mx, b.rmax, 12);
+        if (b.left < 0) nd[l].l = nd[l].r = -1;
+        if (b.right < 0) nd[r].l = nd[r].r = -1;
+        nd[k].l = (int32_t)l;
+        nd[k].r = (int32_t)r;
+    }
+    {
+        Node& root = nd[(size_t)*root_ref];
+        for (int a = 0; a < 3; a++) {
+            root.mn[a] = std::min(nd[(size_t)root.l].mn[a], nd[(size_t)root.r].mn[a]);
+            root.mx[a] = std::max(nd[(size_t)root.l].mx[a], nd[(size_t)root.r].mx[a]);
+        }
+    }
+    auto joint_area = [&](int32_t a, int32_t b) {
+        float mn[3], mx[3];
+        for (int k = 0; k < 3; k++) {
+            mn[k] = std::min(nd[(size_t)a].mn[k], nd[(size_t)b].mn[k]);
+            mx[k] = std::max(nd[(size_t)a].mx[k], nd[(size_t)b].mx[k]);
+        }
+        return half_area(mn, mx);
+    };
+    auto refit = [&](int32_t n) {
+        Node& x = nd[(size_t)n];
+        for (int k = 0; k < 3; k++) {
+            x.mn[k] = std::min(nd[(size_t)x.l].mn[k], nd[(size_t)x.r].mn[k]);
+            x.mx[k] = std::max(nd[(size_t)x.l].mx[k], nd[(size_t)x.r].mx[k]);
+        }
+    };
+    // children carry larger indices than their parents until the first exchange; afterwards the order of
+    // visits is only a heuristic, every exchange is still exact
+    for (uint32_t round = 0; round < rounds; round++) {
+        size_t changed = 0;
+        for (size_t k = inner; k-- > 0;) {
+            Node& n = nd[k];
+            float best = 0.0f;
+            int which = -1;
+            for (int side = 0; side < 2; side++) {
+                int32_t mid = side ? n.r : n.l, other = side ? n.l : n.r;
+                if (nd[(size_t)mid].l < 0) continue; // a leaf has no grandchildren to offer
+                float now = half_area(nd[(size_t)mid].mn, nd[(size_t)mid].mx);
+                // exchange `other` with mid's left (mid keeps its right) or with mid's right
+                float g0 = now - joint_area(other, nd[(size_t)mid].r), g1 = now - joint_area(other, nd[(size_t)mid].l);
+                if (g0 > best) {
+                    best = g0;
+                    which = 2 * side;
+                }
+                if (g1 > best) {
+                    best = g1;
+                    which = 2 * side + 1;
+                }
+            }
+            if (which < 0) continue;
+            int side = which >> 1;
+            int32_t& mid = side ? n.r : n.l;
+            int32_t& other = side ? n.l : n.r;
+            int32_t& grand = (which & 1) ? nd[(size_t)mid].r : nd[(size_t)mid].l;
+            std::swap(other, grand);
+            refit(mid);
+            changed++;
+        }
+        if (changed == 0) break;
+    }
+    // lay the tree out again
+    SubTree out;
+    out.nodes.reserve(inner);
+    out.order.reserve(tree.order.size());
+    struct Frame {
+        int32_t node;
+        int32_t emitted; // index in out.nodes
+        int stage;
+    };
+    uint32_t depth_seen = 0;
+    std::function<int32_t(int32_t, uint32_t)> emit = [&](int32_t n, uint32_t depth) -> int32_t {
+        depth_seen = std::max(depth_seen, depth);
+        const Node& x = nd[(size_t)n];
+        if (x.l < 0) {
+            uint32_t first = (uint32_t)out.order.size();
+            out.order.push_back(tree.order[(size_t)n - inner]);
+            return ptk::bvh_make_leaf(first, 1);
+        }
+        int32_t me = (int32_t)out.nodes.size();
+        out.nodes.emplace_back();
+        int32_t l = emit(x.l, depth + 1), r = emit(x.r, depth + 1);
+        ptk::BvhNode& b = out.nodes[(size_t)me];
+        memcpy(b.lmin, nd[(size_t)x.l].mn, 12);
+        memcpy(b.lmax, nd[(size_t)x.l].mx, 12);
+        memcpy(b.rmin, nd[(size_t)x.r].mn, 12);
+        memcpy(b.rmax, nd[(size_t)x.r].mx, 12);
+        b.left = l;
+        b.right = r;
+        b.pad[0] = b.pad[1] = 0;
+        return me;
+    };
+    int32_t new_root = emit(*root_ref, 0);
+    if (depth_seen > (uint32_t)ptk::kBvhMaxDepth) return; // keep the tree as it was
+    *root_ref = new_root;
+    tree.nodes = std::move(out.nodes);
+    tree.order = std::move(out.order);
+    tree.max_depth = depth_seen;
+}
+
+// The tree with every subtree that the plan turns into a leaf replaced by that leaf.  A subtree's triangles
+// are adjacent in `order` (the build is depth-first), so the leaf is the range from its first triangle on.
+void collapse_leaves(SubTree& tree, int32_t* root_ref, uint32_t max_leaf, float tri_cost) {
+    if (*root_ref < 0 || tree.nodes.empty()) return;
+    WidePlan plan(tree.nodes, max_leaf, tri_cost);
+    const size_t n = tree.nodes.size();
+    std::vector<uint8_t> is_leaf(n, 0);
+    {
+        struct Item {
+            int32_t node;
+            int slots;
+        };
+        std::vector<Item> st{{*root_ref, 1}};
+        while (!st.empty()) {
+            Item it = st.back();
+            st.pop_back();
+            if (it.node < 0) continue;
+            const ptk::BvhNode& nd = tree.nodes[(size_t)it.node];
+            int j = plan.choice[3 * (size_t)it.node + it.slots - 1];
+            if (it.slots == 1) {
+                if (j == 0) {
+                    is_leaf[(size_t)it.node] = 1;
+                    continue;
+                }
+                st.push_back({nd.left, j});
+                st.push_back({nd.right, 4 - j});
+            } else if (j == 0) {
+                st.push_back({it.node, it.slots - 1});
+            } else {
+                st.push_back({nd.left, j});
+                st.push_back({nd.right, it.slots - j});
+            }
+        }
+    }
+    std::vector<uint32_t> first(n);
+    for (size_t k = n; k-- > 0;) {
+        int32_t l = tree.nodes[k].left;
+        first[k] = l < 0 ? leaf_first(l) : first[(size_t)l];
+    }
+    std::vector<ptk::BvhNode> kept;
+    kept.reserve(n / 2 + 1);
+    uint32_t depth_seen = 0;
+    std::function<int32_t(int32_t, uint32_t)> copy = [&](int32_t ref, uint32_t depth) -> int32_t {
+        depth_seen = std::max(depth_seen, depth);
+        if (ref < 0) return ref;
+        if (is_leaf[(size_t)ref]) return ptk::bvh_make_leaf(first[(size_t)ref], plan.triangles[(size_t)ref]);
+        int32_t me = (int32_t)kept.size();
+        kept.push_back(tree.nodes[(size_t)ref]);
+        int32_t l = copy(tree.nodes[(size_t)ref].left, depth + 1);
+        int32_t r = copy(tree.nodes[(size_t)ref].right, depth + 1);
+        kept[(size_t)me].left = l;
+        kept[(size_t)me].right = r;
+        return me;
+    };
+    *root_ref = copy(*root_ref, 0);
+    tree.nodes = std::move(kept);
+    tree.max_depth = depth_seen;
+}
+
 // Appends `sub` to `dst`, rebasing node indices and leaf offsets; returns the
 // rebased reference of sub's root (`root`).
 int32_t append_subtree(SubTree& dst, const SubTree& sub, int32_t root) {
@@ -185,7 +500,7 @@ struct TreeHeader {
     float bmin[3], bmax[3];
     uint64_t geometry_hash; // FNV-1a of the position floats
 };
-constexpr uint32_t kTreeVersion = 1;
+constexpr uint32_t kTreeVersion = 2; // 2: leaves chosen by cost
 
 } // namespace
 
@@ -219,7 +534,26 @@ void padded_triangle_bounds(const float* p, float reach, float* bmin, float* bma
     }
 }
 
+BvhTuning default_bvh_tuning() {
+    BvhTuning t;
+    auto number = [](const char* name, double fallback) {
+        const char* v = std::getenv(name);
+        return v && *v ? std::atof(v) : fallback;
+    };
+    t.bins = std::min(kMaxBins, std::max(2, (int)number("PATHTRACING_AMD_BVH_BINS", t.bins)));
+    t.sweep_below = std::min(kMaxSweep, (uint32_t)std::max(0.0, number("PATHTRACING_AMD_BVH_SWEEP", t.sweep_below)));
+    t.tri_cost = (float)std::max(0.01, number("PATHTRACING_AMD_BVH_TRI_COST", t.tri_cost));
+    t.max_leaf = (uint32_t)std::min((double)ptk::kLeafMaxTris, std::max(1.0, number("PATHTRACING_AMD_BVH_MAX_LEAF", t.max_leaf)));
+    t.collapse = number("PATHTRACING_AMD_BVH_COLLAPSE", t.collapse ? 1 : 0) != 0.0;
+    t.reinsert_passes = (uint32_t)std::max(0.0, number("PATHTRACING_AMD_BVH_REINSERT", t.reinsert_passes));
+    return t;
+}
+
 BuiltBvh build_bvh(const float* positions, uint64_t triangle_count, uint32_t max_leaf) {
+    return build_bvh(positions, triangle_count, max_leaf, default_bvh_tuning());
+}
+
+BuiltBvh build_bvh(const float* positions, uint64_t triangle_count, uint32_t max_leaf, const BvhTuning& tuning) {
     BuiltBvh out;
     if (max_leaf < 1) max_leaf = 1;
     if (max_leaf > (uint32_t)ptk::kLeafMaxTris) max_leaf = ptk::kLeafMaxTris;
@@ -238,7 +572,9 @@ BuiltBvh build_bvh(const float* positions, uint64_t triangle_count, uint32_t max
         for (int k = 0; k < 3; k++) refs[i].c[k] = 0.5f * (refs[i].bmin[k] + refs[i].bmax[k]);
         refs[i].idx = (uint32_t)i;
     }
-    Builder B{refs, max_leaf};
+    // With the cost-driven choice of leaves the binary tree goes down to single triangles first.
+    Builder B{refs, tuning.collapse ? 1u : max_leaf, std::min(kMaxBins, std::max(2, tuning.bins)),
+              std::min(kMaxSweep, tuning.sweep_below)};
     Box bounds;
     SubTree tree;
     if (triangle_count < 200000) {
@@ -307,6 +643,10 @@ BuiltBvh build_bvh(const float* positions, uint64_t triangle_count, uint32_t max
         };
         out.root_ref = emit(top_root, &bounds);
     }
+    if (tuning.collapse) {
+        rotate_tree(tree, &out.root_ref, tuning.reinsert_passes);
+        collapse_leaves(tree, &out.root_ref, max_leaf, tuning.tri_cost);
+    }
     out.nodes = std::move(tree.nodes);
     out.order = std::move(tree.order);
     out.max_depth = tree.max_depth;
@@ -318,17 +658,15 @@ BuiltBvh build_bvh(const float* positions, uint64_t triangle_count, uint32_t max
     return out;
 }
 
-WideBvh widen_bvh(const BuiltBvh& bvh) {
+WideBvh widen_bvh(const BuiltBvh& bvh) { return widen_bvh(bvh, default_bvh_tuning()); }
+
+WideBvh widen_bvh(const BuiltBvh& bvh, const BvhTuning& tuning) {
     WideBvh out;
     out.root_ref = bvh.root_ref;
     if (bvh.root_ref < 0 || bvh.root_ref == ptk::kBvhSentinel) return out; // empty mesh or a single leaf
     struct Child {
         int32_t ref;
         float mn[3], mx[3];
-    };
-    auto half_area = [](const Child& c) {
-        float dx = c.mx[0] - c.mn[0], dy = c.mx[1] - c.mn[1], dz = c.mx[2] - c.mn[2];
-        return dx * dy + dy * dz + dz * dx;
     };
     auto children_of = [&](int32_t node, Child* two) {
         const ptk::BvhNode& nd = bvh.nodes[node];
@@ -339,24 +677,52 @@ WideBvh widen_bvh(const BuiltBvh& bvh) {
         memcpy(two[1].mn, nd.rmin, 12);
         memcpy(two[1].mx, nd.rmax, 12);
     };
+    // The leaves are what the file says; only the children of the wide nodes are chosen here (max_leaf 0).
+    std::unique_ptr<WidePlan> plan;
+    if (tuning.collapse) plan.reset(new WidePlan(bvh.nodes, 0, tuning.tri_cost));
+    // The children the plan gives `c` when it may take `slots` slots of the node being assembled.
+    std::function<void(const Child&, int, Child*, int*)> spread = [&](const Child& c, int slots, Child* into, int* n) {
+        int j = c.ref < 0 ? 0 : plan->choice[3 * (size_t)c.ref + slots - 1];
+        if (c.ref < 0 || (slots == 1)) {
+            into[(*n)++] = c;
+            return;
+        }
+        if (j == 0) {
+            spread(c, slots - 1, into, n);
+            return;
+        }
+        Child two[2];
+        children_of(c.ref, two);
+        spread(two[0], j, into, n);
+        spread(two[1], slots - j, into, n);
+    };
     // returns {wide index, stack need below}
     std::function<uint32_t(int32_t, int32_t*)> emit = [&](int32_t node, int32_t* index) -> uint32_t {
         Child c[4];
         int n = 2;
         children_of(node, c);
-        while (n < 4) {
-            int pick = -1;
-            float best = -1.0f;
-            for (int i = 0; i < n; i++)
-                if (c[i].ref >= 0 && half_area(c[i]) > best) {
-                    best = half_area(c[i]);
-                    pick = i;
-                }
-            if (pick < 0) break;
-            Child two[2];
-            children_of(c[pick].ref, two);
-            c[pick] = two[0];
-            c[n++] = two[1];
+        if (plan) {
+            Child two[2] = {c[0], c[1]};
+            int j = plan->choice[3 * (size_t)node];
+            if (j == 0) j = 2; // the plan would make this node a leaf: only the root of a tiny mesh gets here
+            n = 0;
+            spread(two[0], j, c, &n);
+            spread(two[1], 4 - j, c, &n);
+        } else {
+            while (n < 4) {
+                int pick = -1;
+                float best = -1.0f;
+                for (int i = 0; i < n; i++)
+                    if (c[i].ref >= 0 && half_area(c[i].mn, c[i].mx) > best) {
+                        best = half_area(c[i].mn, c[i].mx);
+                        pick = i;
+                    }
+                if (pick < 0) break;
+                Child two[2];
+                children_of(c[pick].ref, two);
+                c[pick] = two[0];
+                c[n++] = two[1];
+            }
         }
         int32_t me = (int32_t)out.nodes.size();
         *index = me;

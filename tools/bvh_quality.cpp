@@ -2,9 +2,9 @@
 // (host/bvh.cpp: build_bvh + widen_bvh), sends rays of the kinds a render sends through a CPU restatement of the
 // device's search (pt_device.h: trav_inner / trav_leaf -- same child order, same pruning, same quantised boxes) and
 // reports node records and triangle records fetched per search, next to the tree's surface-area cost.
-//   g++ -O2 -std=c++17 -I pathtracing_amd/csrc tools/bvh_quality.cpp pathtracing_amd/csrc/host/bvh.cpp \
-//       pathtracing_amd/csrc/host/obj_loader.cpp -pthread -o /tmp/bvh_quality
-//   /tmp/bvh_quality /tmp/pathtracing_amd_dragon/dragon.obj [rays]
+//   g++ -O2 -std=c++17 -I pathtracing_amd/csrc -I include tools/bvh_quality.cpp pathtracing_amd/csrc/host/bvh.cpp,
+//       then pathtracing_amd/csrc/host/obj_loader.cpp -pthread -o /tmp/bvh_quality (one command line)
+//   /tmp/bvh_quality /tmp/pathtracing_amd_dragon/dragon.obj [rays per kind] [most triangles per leaf]
 // Rays: (a) camera rays of the benchmark's view (origin (0,2,70) in mesh space, aimed at the mesh's box), (b) bounce
 // rays leaving random triangles into the hemisphere of their normal, (c) rays from random points of a box around the
 // mesh (the room's walls) into random inward directions.  Only rays that reach the mesh's bounds count as searches.
@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <random>
 #include <string>
 #include <vector>
@@ -185,11 +186,157 @@ void sah_cost(const pt::WideBvh& w, double* node_cost, double* tri_cost) {
     *tri_cost = tris;
 }
 
+
+// ---- what wider nodes would visit: the same binary tree cut into nodes of up to W children by the same
+// minimum-surface-area-cost rule (host/bvh.cpp: WidePlan, here for any W), searched nearest child first with
+// exact boxes.  W = 4 through this route shows what the device's 8-bit boxes cost; W = 8 is the estimate for
+// a 128-byte node.
+struct NaryNode {
+    int n = 0;
+    float mn[8][3], mx[8][3];
+    int32_t child[8]; // >= 0: NaryNode index, < 0: leaf reference as in the binary tree
+};
+
+std::vector<NaryNode> cut_wide(const pt::BuiltBvh& bvh, int W, float tri_cost) {
+    const size_t n = bvh.nodes.size();
+    const int S = W - 1; // slots a subtree can be given by the node above
+    std::vector<float> cost(n * S), area(n);
+    std::vector<uint8_t> choice(n * S);
+    auto ha = [](const float* mn, const float* mx) {
+        float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    auto side = [&](int32_t ref, const float* mn, const float* mx, float* c) {
+        if (ref < 0) {
+            float v = ha(mn, mx) * (float)((((uint32_t)~ref) & 7u) + 1u) * tri_cost;
+            for (int i = 0; i < S; i++) c[i] = v;
+        } else {
+            for (int i = 0; i < S; i++) c[i] = cost[(size_t)ref * S + i];
+        }
+    };
+    for (size_t k = n; k-- > 0;) {
+        const ptk::BvhNode& nd = bvh.nodes[k];
+        float cl[8], cr[8], mn[3], mx[3];
+        side(nd.left, nd.lmin, nd.lmax, cl);
+        side(nd.right, nd.rmin, nd.rmax, cr);
+        for (int a = 0; a < 3; a++) {
+            mn[a] = std::min(nd.lmin[a], nd.rmin[a]);
+            mx[a] = std::max(nd.lmax[a], nd.rmax[a]);
+        }
+        area[k] = ha(mn, mx);
+        float spread[9];
+        uint8_t at[9];
+        for (int slots = 2; slots <= W; slots++) {
+            spread[slots] = INFINITY;
+            at[slots] = 1;
+            for (int j = 1; j < slots; j++) {
+                if (j > S || slots - j > S) continue;
+                float c = cl[j - 1] + cr[slots - j - 1];
+                if (c < spread[slots]) {
+                    spread[slots] = c;
+                    at[slots] = (uint8_t)j;
+                }
+            }
+        }
+        cost[k * S] = area[k] + spread[W];
+        choice[k * S] = at[W];
+        for (int i = 2; i <= S; i++) {
+            if (spread[i] < cost[k * S + i - 2]) {
+                cost[k * S + i - 1] = spread[i];
+                choice[k * S + i - 1] = at[i];
+            } else {
+                cost[k * S + i - 1] = cost[k * S + i - 2];
+                choice[k * S + i - 1] = 0;
+            }
+        }
+    }
+    std::vector<NaryNode> out;
+    struct Child {
+        int32_t ref;
+        const float *mn, *mx;
+    };
+    std::function<void(Child, int, NaryNode&)> spread_into = [&](Child c, int slots, NaryNode& w) {
+        int j = c.ref < 0 ? 0 : choice[(size_t)c.ref * S + slots - 1];
+        if (c.ref < 0 || slots == 1) {
+            memcpy(w.mn[w.n], c.mn, 12);
+            memcpy(w.mx[w.n], c.mx, 12);
+            w.child[w.n++] = c.ref; // inner references are resolved by the caller
+            return;
+        }
+        if (j == 0) return spread_into(c, slots - 1, w);
+        const ptk::BvhNode& nd = bvh.nodes[(size_t)c.ref];
+        spread_into({nd.left, nd.lmin, nd.lmax}, j, w);
+        spread_into({nd.right, nd.rmin, nd.rmax}, slots - j, w);
+    };
+    std::function<int32_t(int32_t)> emit = [&](int32_t node) -> int32_t {
+        int32_t me = (int32_t)out.size();
+        out.emplace_back();
+        NaryNode w;
+        const ptk::BvhNode& nd = bvh.nodes[(size_t)node];
+        int j = choice[(size_t)node * S];
+        spread_into({nd.left, nd.lmin, nd.lmax}, j, w);
+        spread_into({nd.right, nd.rmin, nd.rmax}, W - j, w);
+        for (int i = 0; i < w.n; i++)
+            if (w.child[i] >= 0) w.child[i] = emit(w.child[i]);
+        out[(size_t)me] = w;
+        return me;
+    };
+    if (bvh.root_ref >= 0 && bvh.root_ref != ptk::kBvhSentinel) emit(bvh.root_ref);
+    return out;
+}
+
+void search_wide(const std::vector<NaryNode>& nodes, const std::vector<uint32_t>& order, const float* positions, const Ray& r,
+                 Stats& s) {
+    float inv[3];
+    for (int k = 0; k < 3; k++) inv[k] = std::min(1e28f, std::max(-1e28f, 1.0f / r.d[k]));
+    float tbest = INFINITY;
+    int32_t stack[256];
+    int sp = 0;
+    int32_t cur = 0;
+    while (cur != ptk::kBvhSentinel) {
+        if (cur >= 0) {
+            const NaryNode& n = nodes[(size_t)cur];
+            s.nodes++;
+            float t[8];
+            int idx[8], hits = 0;
+            for (int c = 0; c < n.n; c++) {
+                float lo = 0.0f, hi = tbest;
+                for (int k = 0; k < 3; k++) {
+                    float a = (n.mn[c][k] - r.o[k]) * inv[k], b = (n.mx[c][k] - r.o[k]) * inv[k];
+                    lo = std::max(lo, std::min(a, b));
+                    hi = std::min(hi, std::max(a, b));
+                }
+                if (lo <= hi * 1.0000004f) {
+                    t[hits] = lo;
+                    idx[hits++] = c;
+                }
+            }
+            for (int i = 1; i < hits; i++) // farthest first, so the nearest is popped first
+                for (int j = i; j > 0 && t[j] > t[j - 1]; j--) {
+                    std::swap(t[j], t[j - 1]);
+                    std::swap(idx[j], idx[j - 1]);
+                }
+            for (int i = 0; i < hits; i++) stack[sp++] = n.child[idx[i]];
+            cur = sp ? stack[--sp] : ptk::kBvhSentinel;
+        } else {
+            uint32_t raw = (uint32_t)(~cur), first = raw >> 3, count = (raw & 7u) + 1u;
+            s.leaves++;
+            for (uint32_t k = 0; k < count; k++) {
+                s.tris++;
+                float t;
+                if (triangle_hit(positions + 9 * (size_t)order[first + k], r, &t) && t < tbest) tbest = t;
+            }
+            cur = sp ? stack[--sp] : ptk::kBvhSentinel;
+        }
+    }
+    s.searches++;
+}
+
 } // namespace
 
 int main(int argc, char** argv) {
     if (argc < 2) {
-        fprintf(stderr, "usage: bvh_quality MESH.obj [rays per kind]\n");
+        fprintf(stderr, "usage: bvh_quality MESH.obj [rays per kind] [most triangles per leaf]\n");
         return 2;
     }
     const size_t per_kind = argc > 2 ? (size_t)atol(argv[2]) : 200000;
@@ -204,7 +351,8 @@ int main(int argc, char** argv) {
     const float* pos = mesh.positions.data();
     const uint64_t nt = mesh.triangle_count;
     auto t0 = std::chrono::steady_clock::now();
-    pt::BuiltBvh bvh = pt::build_bvh(pos, nt, 4);
+    const uint32_t max_leaf = argc > 3 ? (uint32_t)atoi(argv[3]) : 4;
+    pt::BuiltBvh bvh = pt::build_bvh(pos, nt, max_leaf);
     auto t1 = std::chrono::steady_clock::now();
     pt::WideBvh wide = pt::widen_bvh(bvh);
     auto t2 = std::chrono::steady_clock::now();
@@ -232,6 +380,7 @@ int main(int argc, char** argv) {
     };
     const char* names[3] = {"camera rays", "bounce rays off the mesh", "rays from the room's walls"};
     Stats total;
+    std::vector<Ray> all_rays;
     for (int kind = 0; kind < 3; kind++) {
         Stats s;
         size_t made = 0, tried = 0;
@@ -272,6 +421,7 @@ int main(int argc, char** argv) {
             }
             if (!reaches(bvh.bmin, bvh.bmax, r)) continue;
             made++;
+            all_rays.push_back(r);
             search(wide, bvh.order, pos, r, s);
         }
         printf("%-28s %8.0f searches (%5.1f %% of the rays tried), %5.1f %% hit: %6.2f node records  %6.2f triangle records  %5.2f leaves  per search; deepest stack %.0f\n",
@@ -285,5 +435,16 @@ int main(int argc, char** argv) {
     printf("%-28s %8.0f searches: %6.2f node records  %6.2f triangle records  %5.2f leaves  per search  -> %.0f B per search (64 B nodes, 48 B triangles)\n",
            "all", total.searches, total.nodes / total.searches, total.tris / total.searches, total.leaves / total.searches,
            (64.0 * total.nodes + 48.0 * total.tris) / total.searches);
+    const float cut_tri_cost = pt::default_bvh_tuning().tri_cost;
+    for (int W : {4, 8}) {
+        std::vector<NaryNode> nodes = cut_wide(bvh, W, cut_tri_cost);
+        if (nodes.empty()) continue;
+        Stats s;
+        for (const Ray& r : all_rays) search_wide(nodes, bvh.order, pos, r, s);
+        size_t kids = 0;
+        for (const NaryNode& n : nodes) kids += (size_t)n.n;
+        printf("%d-wide nodes with exact boxes: %zu nodes (%.2f children each): %6.2f node records  %6.2f triangle records  %5.2f leaves  per search\n",
+               W, nodes.size(), (double)kids / nodes.size(), s.nodes / s.searches, s.tris / s.searches, s.leaves / s.searches);
+    }
     return 0;
 }
