@@ -265,6 +265,19 @@ pub struct PtFrame {
 pub struct PtWorker {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct PtServer {
+    _private: [u8; 0],
+}
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct PtServerStats {
+    pub connections: u64,
+    pub handshakes: u64,
+    pub messages_answered: u64,
+    pub messages_failed: u64,
+    pub datagrams_answered: u64,
+}
 
 extern "C" {
     pub fn pt_last_error(buf: *mut c_char, cap: usize) -> usize;
@@ -393,6 +406,28 @@ extern "C" {
         opts: *const PtRenderOpts,
         out_bytes: *mut *mut u8,
         out_size: *mut u64,
+    ) -> PtStatus;
+    pub fn pt_worker_serve_start(
+        worker: *mut PtWorker,
+        bind_addr: *const c_char,
+        websocket_port: u16,
+        udp_port: u16,
+        out_server: *mut *mut PtServer,
+    ) -> PtStatus;
+    pub fn pt_server_ports(server: *const PtServer, out_websocket_port: *mut u16, out_udp_port: *mut u16) -> PtStatus;
+    pub fn pt_server_stats(
+        server: *const PtServer,
+        out_stats: *mut PtServerStats,
+        last_error: *mut c_char,
+        last_error_cap: usize,
+    ) -> PtStatus;
+    pub fn pt_server_stop(server: *mut PtServer);
+    pub fn pt_worker_serve(
+        worker: *mut PtWorker,
+        bind_addr: *const c_char,
+        websocket_port: u16,
+        udp_port: u16,
+        stop_flag: *const i32,
     ) -> PtStatus;
     pub fn pt_frame_create(width: u32, height: u32, device: c_int, out_frame: *mut *mut PtFrame) -> PtStatus;
     pub fn pt_frame_destroy(frame: *mut PtFrame);

@@ -417,7 +417,7 @@ PtStatus pt_rendered_image_to_bytes(const float* rgb, uint32_t width, uint32_t h
 PtStatus pt_rendered_image_from_bytes(const uint8_t* bytes, size_t size, uint32_t* out_width,
                                       uint32_t* out_height, float* out_rgb, size_t out_cap_floats);
 
-/* -------------------------------------- the worker's front end, without sockets */
+/* ------------------------------------------------ the worker's front end */
 
 /* worker::discovery::{Request, Response} (worker/src/lib.rs:81-91) in the wire format the
  * reference uses for them, postcard 1.1: the worker answers every datagram on UDP port
@@ -456,6 +456,43 @@ uint32_t pt_worker_cached_scene_count(const PtWorker* worker);
  * the reference then drops the connection.  opts may be NULL. */
 PtStatus pt_worker_handle_message(PtWorker* worker, const char* task_json, const PtRenderOpts* opts,
                                   uint8_t** out_bytes, uint64_t* out_size);
+
+/* The worker's two sockets (worker/src/main.rs:36-113).  A TCP listener on websocket_port
+ * (main.rs:17: 30000) whose connections are upgraded to WebSockets (RFC 6455; what
+ * tokio_tungstenite::accept_async does, main.rs:53-55) and then run connection_loop
+ * (main.rs:68-93): one text frame holding a RenderTask in, pt_worker_handle_message, one
+ * binary frame holding RenderedImage::to_bytes out, until a round fails -- a frame that is
+ * not text ("Unexpected message format"), a task that does not decode or a render that fails
+ * ends that connection and no other (main.rs:60-65).  A UDP socket on udp_port (main.rs:18:
+ * 40000, SO_BROADCAST) answers every datagram, which is how discovery::Request {} decodes
+ * (main.rs:95-113), with the postcard bytes of Response { websocket_port } naming the port
+ * that was actually bound.  Port 0 binds any free port; bind_addr NULL is "0.0.0.0"
+ * (main.rs:37,96).  Renders of all connections take turns behind the worker's lock
+ * (main.rs:32,82).  Differences from the reference, all on the tolerant side: a ping is
+ * answered with a pong and the connection goes on (tungstenite hands the ping to
+ * connection_loop, which gives up on it), a close frame is answered with a close frame, and
+ * a client that disconnects ends its connection thread quietly (main.rs:72 panics the task).
+ * The worker must outlive the server. */
+typedef struct PtServer PtServer;
+typedef struct PtServerStats {
+    uint64_t connections;        /* TCP connections accepted */
+    uint64_t handshakes;         /* of those, upgraded to a WebSocket */
+    uint64_t messages_answered;  /* rounds of connection_loop that sent a binary frame */
+    uint64_t messages_failed;    /* rounds that ended their connection */
+    uint64_t datagrams_answered; /* discovery requests answered */
+} PtServerStats;
+PtStatus pt_worker_serve_start(PtWorker* worker, const char* bind_addr, uint16_t websocket_port, uint16_t udp_port,
+                               PtServer** out_server);
+PtStatus pt_server_ports(const PtServer* server, uint16_t* out_websocket_port, uint16_t* out_udp_port);
+/* Counters so far; last_error (may be NULL) receives the message of the round or handshake
+ * that failed last ("Error during message exchange: ..." in the reference's log). */
+PtStatus pt_server_stats(const PtServer* server, PtServerStats* out_stats, char* last_error, size_t last_error_cap);
+/* Closes both sockets, ends the open connections, joins the threads, frees the server. */
+void pt_server_stop(PtServer* server);
+/* start_ws (main.rs:36-48) as one blocking call: serves until *stop_flag becomes non-zero
+ * (read as a volatile ten times a second; NULL = until the process ends). */
+PtStatus pt_worker_serve(PtWorker* worker, const char* bind_addr, uint16_t websocket_port, uint16_t udp_port,
+                         const int32_t* stop_flag);
 
 /* ------------------------------------------------- the client's frame sum */
 

@@ -258,9 +258,36 @@ public:
         return out;
     }
     uint32_t cached_scenes() const { return pt_worker_cached_scene_count(handle_); }
+    PtWorker* handle() const { return handle_; }
 
 private:
     PtWorker* handle_ = nullptr;
+};
+
+// start_ws (main.rs:36-48): the WebSocket listener and the UDP discovery responder over a worker, served by the
+// library's own threads until the object goes away.  Port 0 = any free port.  The worker must outlive it.
+class Server {
+public:
+    Server(WorkerFrontEnd& worker, uint16_t websocket_port = 30000, uint16_t udp_port = 40000, const std::string& bind_addr = "0.0.0.0") {
+        check(pt_worker_serve_start(worker.handle(), bind_addr.c_str(), websocket_port, udp_port, &handle_));
+        check(pt_server_ports(handle_, &websocket_port_, &udp_port_));
+    }
+    Server(const Server&) = delete;
+    Server& operator=(const Server&) = delete;
+    ~Server() { pt_server_stop(handle_); }
+    uint16_t websocket_port() const { return websocket_port_; }
+    uint16_t udp_port() const { return udp_port_; }
+    PtServerStats stats(std::string* last_error = nullptr) const {
+        PtServerStats st{};
+        char message[512] = {0};
+        check(pt_server_stats(handle_, &st, message, sizeof(message)));
+        if (last_error) *last_error = message;
+        return st;
+    }
+
+private:
+    PtServer* handle_ = nullptr;
+    uint16_t websocket_port_ = 0, udp_port_ = 0;
 };
 
 } // namespace pt

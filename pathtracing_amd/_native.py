@@ -207,6 +207,16 @@ class PtHit(C.Structure):
 
 # Every symbol include/pathtracing_amd.h declares: name -> (restype, argtypes)
 _VOIDP = C.c_void_p
+class PtServerStats(C.Structure):
+    _fields_ = [
+        ("connections", C.c_uint64),
+        ("handshakes", C.c_uint64),
+        ("messages_answered", C.c_uint64),
+        ("messages_failed", C.c_uint64),
+        ("datagrams_answered", C.c_uint64),
+    ]
+
+
 SYMBOLS = {
     "pt_last_error": (C.c_size_t, [C.c_char_p, C.c_size_t]),
     "pt_abi_version": (C.c_uint32, []),
@@ -251,6 +261,11 @@ SYMBOLS = {
     "pt_worker_cached_scene_count": (C.c_uint32, [_VOIDP]),
     "pt_worker_handle_message": (C.c_int, [_VOIDP, C.c_char_p, C.POINTER(PtRenderOpts), C.POINTER(C.POINTER(C.c_uint8)),
                                           C.POINTER(C.c_uint64)]),
+    "pt_worker_serve_start": (C.c_int, [_VOIDP, C.c_char_p, C.c_uint16, C.c_uint16, C.POINTER(_VOIDP)]),
+    "pt_server_ports": (C.c_int, [_VOIDP, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16)]),
+    "pt_server_stats": (C.c_int, [_VOIDP, C.POINTER(PtServerStats), C.c_char_p, C.c_size_t]),
+    "pt_server_stop": (None, [_VOIDP]),
+    "pt_worker_serve": (C.c_int, [_VOIDP, C.c_char_p, C.c_uint16, C.c_uint16, C.POINTER(C.c_int32)]),
     "pt_frame_create": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_VOIDP)]),
     "pt_frame_destroy": (None, [_VOIDP]),
     "pt_frame_add_render": (C.c_int, [_VOIDP, _VOIDP]),

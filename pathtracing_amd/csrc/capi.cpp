@@ -20,6 +20,7 @@
 #include "../../include/pathtracing_amd.h"
 #include "host/bvh.hpp"
 #include "host/front_end.hpp"
+#include "host/listener.hpp"
 #include "host/host_scene.hpp"
 #include "host/xform.hpp"
 #include "kernels/pt_kernels.h"
@@ -1616,6 +1617,78 @@ PtStatus pt_worker_handle_message(PtWorker* worker, const char* task_json, const
         guard.p = nullptr;
     });
     return st;
+}
+
+struct PtServer {
+    std::unique_ptr<pt::Server> server;
+};
+
+PtStatus pt_worker_serve_start(PtWorker* worker, const char* bind_addr, uint16_t websocket_port, uint16_t udp_port,
+                               PtServer** out_server) {
+    return guarded([&] {
+        if (!worker || !out_server) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        // one round of connection_loop: the text frame through the worker, its bytes as the reply
+        pt::MessageHandler handler = [worker](const std::string& text, std::vector<uint8_t>* reply, std::string* error) {
+            uint8_t* bytes = nullptr;
+            uint64_t size = 0;
+            if (pt_worker_handle_message(worker, text.c_str(), nullptr, &bytes, &size) != PT_OK) {
+                *error = pt::last_error_string();
+                return false;
+            }
+            reply->assign(bytes, bytes + size);
+            pt_buffer_free(bytes);
+            return true;
+        };
+        auto s = std::make_unique<PtServer>();
+        s->server = std::make_unique<pt::Server>(bind_addr && *bind_addr ? bind_addr : "0.0.0.0", websocket_port, udp_port,
+                                                 std::move(handler));
+        *out_server = s.release();
+    });
+}
+
+PtStatus pt_server_ports(const PtServer* server, uint16_t* out_websocket_port, uint16_t* out_udp_port) {
+    return guarded([&] {
+        if (!server) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        if (out_websocket_port) *out_websocket_port = server->server->websocket_port();
+        if (out_udp_port) *out_udp_port = server->server->udp_port();
+    });
+}
+
+PtStatus pt_server_stats(const PtServer* server, PtServerStats* out_stats, char* last_error, size_t last_error_cap) {
+    return guarded([&] {
+        if (!server || !out_stats) throw Error(PT_ERR_INVALID_ARGUMENT, "null argument");
+        const pt::ServerCounters c = server->server->counters();
+        out_stats->connections = c.connections;
+        out_stats->handshakes = c.handshakes;
+        out_stats->messages_answered = c.messages_answered;
+        out_stats->messages_failed = c.messages_failed;
+        out_stats->datagrams_answered = c.datagrams_answered;
+        if (last_error && last_error_cap) {
+            const std::string e = server->server->last_error();
+            const size_t n = std::min(e.size(), last_error_cap - 1);
+            memcpy(last_error, e.data(), n);
+            last_error[n] = 0;
+        }
+    });
+}
+
+void pt_server_stop(PtServer* server) {
+    if (!server) return;
+    try {
+        server->server->stop();
+    } catch (...) {
+    }
+    delete server;
+}
+
+PtStatus pt_worker_serve(PtWorker* worker, const char* bind_addr, uint16_t websocket_port, uint16_t udp_port,
+                         const int32_t* stop_flag) {
+    PtServer* server = nullptr;
+    PtStatus st = pt_worker_serve_start(worker, bind_addr, websocket_port, udp_port, &server);
+    if (st != PT_OK) return st;
+    while (!stop_flag || *static_cast<const volatile int32_t*>(stop_flag) == 0) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    pt_server_stop(server);
+    return PT_OK;
 }
 
 PtStatus pt_frame_create(uint32_t width, uint32_t height, int device, PtFrame** out_frame) {

@@ -545,7 +545,7 @@ BvhTuning default_bvh_tuning() {
     t.tri_cost = (float)std::max(0.01, number("PATHTRACING_AMD_BVH_TRI_COST", t.tri_cost));
     t.max_leaf = (uint32_t)std::min((double)ptk::kLeafMaxTris, std::max(1.0, number("PATHTRACING_AMD_BVH_MAX_LEAF", t.max_leaf)));
     t.collapse = number("PATHTRACING_AMD_BVH_COLLAPSE", t.collapse ? 1 : 0) != 0.0;
-    t.reinsert_passes = (uint32_t)std::max(0.0, number("PATHTRACING_AMD_BVH_REINSERT", t.reinsert_passes));
+    t.rotation_rounds = (uint32_t)std::max(0.0, number("PATHTRACING_AMD_BVH_ROTATE", t.rotation_rounds));
     return t;
 }
 
@@ -644,7 +644,7 @@ BuiltBvh build_bvh(const float* positions, uint64_t triangle_count, uint32_t max
         out.root_ref = emit(top_root, &bounds);
     }
     if (tuning.collapse) {
-        rotate_tree(tree, &out.root_ref, tuning.reinsert_passes);
+        rotate_tree(tree, &out.root_ref, tuning.rotation_rounds);
         collapse_leaves(tree, &out.root_ref, max_leaf, tuning.tri_cost);
     }
     out.nodes = std::move(tree.nodes);

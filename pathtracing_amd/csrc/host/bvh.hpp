@@ -30,10 +30,10 @@ struct BvhTuning {
     uint32_t max_leaf = 4;      // most triangles a leaf may hold (<= 8); what the library passes to build_bvh
     bool collapse = true;       // leaves and wide-node children chosen by minimum surface-area cost;
                                 // false: every range of <= max_leaf triangles is a leaf, widest-box-first widening
-    uint32_t reinsert_passes = 0; // rounds of subtree reinsertion over the binary tree before leaves are chosen
+    uint32_t rotation_rounds = 0; // rounds of tree rotations over the binary tree before leaves are chosen (find nothing on uniform meshes)
 };
 // Defaults, each overridable by an environment variable (PATHTRACING_AMD_BVH_BINS, _SWEEP, _TRI_COST,
-// _MAX_LEAF, _COLLAPSE, _REINSERT) so that measuring scripts can compare trees without rebuilding the library.
+// _MAX_LEAF, _COLLAPSE, _ROTATE) so that measuring scripts can compare trees without rebuilding the library.
 BvhTuning default_bvh_tuning();
 
 // Surface-area-heuristic BVH2, at most `max_leaf` (<= 8) triangles per leaf, depth

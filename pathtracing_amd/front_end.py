@@ -1,8 +1,9 @@
-"""The reference worker's front end without its sockets (``worker/src/main.rs:36-113``):
-the discovery messages in their postcard wire format, the scene digest that names a scene's
-file bucket (``client/src/scene.rs:19-85``), and one round of ``connection_loop`` -- a
-``RenderTask`` text frame in, the ``RenderedImage`` binary frame out -- over a ``Worker``
-whose ``FileStore`` buckets are directories named by ``scene_md5``."""
+"""The reference worker's front end (``worker/src/main.rs:36-113``): the discovery messages
+in their postcard wire format, the scene digest that names a scene's file bucket
+(``client/src/scene.rs:19-85``), one round of ``connection_loop`` -- a ``RenderTask`` text
+frame in, the ``RenderedImage`` binary frame out -- over a ``Worker`` whose ``FileStore``
+buckets are directories named by ``scene_md5``, and the two sockets themselves (``Server``:
+WebSocket listener + UDP discovery responder)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -74,6 +75,10 @@ class WorkerFrontEnd:
     def cached_scene_count(self) -> int:
         return int(N.lib.pt_worker_cached_scene_count(self._handle))
 
+    def serve(self, websocket_port: int = WEBSOCKET_PORT, udp_port: int = BROADCAST_PORT, bind_addr: str = "0.0.0.0") -> "Server":
+        """``start_ws`` (``main.rs:36-48``): both sockets open and served by the library's threads until ``stop()``."""
+        return Server(self, websocket_port, udp_port, bind_addr)
+
     def close(self) -> None:
         if self._handle:
             N.lib.pt_worker_destroy(self._handle)
@@ -82,5 +87,44 @@ class WorkerFrontEnd:
     def __del__(self):
         try:
             self.close()
+        except Exception:
+            pass
+
+
+class Server:
+    """The worker's listeners (``worker/src/main.rs:36-113``) over a ``WorkerFrontEnd``; port 0 binds any free port."""
+
+    def __init__(self, worker: WorkerFrontEnd, websocket_port: int = WEBSOCKET_PORT, udp_port: int = BROADCAST_PORT,
+                 bind_addr: str = "0.0.0.0"):
+        self._worker = worker  # the worker must outlive the server
+        h = C.c_void_p()
+        N.check(N.lib.pt_worker_serve_start(worker._handle, bind_addr.encode(), websocket_port, udp_port, C.byref(h)))
+        self._handle = h
+        ws, udp = C.c_uint16(), C.c_uint16()
+        N.check(N.lib.pt_server_ports(h, C.byref(ws), C.byref(udp)))
+        self.websocket_port, self.udp_port = int(ws.value), int(udp.value)
+
+    def stats(self) -> dict:
+        st = N.PtServerStats()
+        err = C.create_string_buffer(512)
+        N.check(N.lib.pt_server_stats(self._handle, C.byref(st), err, len(err)))
+        out = {name: int(getattr(st, name)) for name, _ in N.PtServerStats._fields_}
+        out["last_error"] = err.value.decode("utf-8", "replace")
+        return out
+
+    def stop(self) -> None:
+        if self._handle:
+            N.lib.pt_server_stop(self._handle)
+            self._handle = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.stop()
+
+    def __del__(self):
+        try:
+            self.stop()
         except Exception:
             pass

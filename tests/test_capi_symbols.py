@@ -35,7 +35,7 @@ def test_struct_layouts_match_the_header(tmp_path):
 
         pytest.skip("no C compiler")
     structs = ["PtVec2", "PtVec3", "PtMat3", "PtMat4", "PtRay", "PtNodeDesc", "PtMeshDesc", "PtMaterialDesc", "PtImageDesc",
-               "PtTreeBlob", "PtSceneDesc", "PtCamera", "PtRenderTask", "PtRenderOpts", "PtRenderStats", "PtHit"]
+               "PtTreeBlob", "PtSceneDesc", "PtCamera", "PtRenderTask", "PtRenderOpts", "PtRenderStats", "PtHit", "PtServerStats"]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pathtracing_amd.h"', "int main(void) {"]
     for name in structs:
         lines.append(f'printf("{name} %zu\\n", sizeof({name}));')

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "pathtracing_amd.h")
 CRATE = os.path.join(ROOT, "bindings", "rust", "pathtracing-amd-sys", "src", "lib.rs")
 
-SCALARS = {"float": "f32", "double": "f64", "uint8_t": "u8", "uint16_t": "u16", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize",
+SCALARS = {"float": "f32", "double": "f64", "uint8_t": "u8", "uint16_t": "u16", "uint32_t": "u32", "int32_t": "i32", "uint64_t": "u64", "size_t": "usize",
            "int": "c_int", "char": "c_char", "void": "c_void", "PtStatus": "PtStatus"}
 
 
@@ -95,11 +95,11 @@ def test_rust_structs_follow_the_header():
     header = _strip_comments(open(HEADER).read())
     crate = _strip_comments(open(CRATE).read())
     c, r = c_structs(header), rust_structs(crate)
-    assert len(c) == 17
+    assert len(c) == 18
     for name, fields in c.items():
         assert name in r, f"struct {name} is missing from the crate"
         assert r[name] == fields, f"struct {name}: header {fields} / crate {r[name]}"
-    for opaque in ("PtScene", "PtHostScene", "PtFrame", "PtWorker"):
+    for opaque in ("PtScene", "PtHostScene", "PtFrame", "PtWorker", "PtServer"):
         assert r[opaque] == [("_private", "[u8; 0]")]
 
 
