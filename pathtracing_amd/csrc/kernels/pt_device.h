@@ -463,7 +463,8 @@ __device__ __forceinline__ void trav_inner(TravState& ts, const Ray& ray, TravSt
     float t1 = child_entry<1>(near_q, far_q, a, bn, bf, limit, r1);
     float t2 = child_entry<2>(near_q, far_q, a, bn, bf, limit, r2);
     float t3 = child_entry<3>(near_q, far_q, a, bn, bf, limit, r3);
-    // sort the four by entry distance (misses, at +inf, end up last)
+    // sort the four by entry distance (misses, at +inf, end up last); finding only the nearest and deferring
+    // the others in slot order saves two comparators and opens 2 % more nodes: no faster
     order_pair(t0, r0, t1, r1);
     order_pair(t2, r2, t3, r3);
     order_pair(t0, r0, t2, r2);

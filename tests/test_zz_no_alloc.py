@@ -1,7 +1,9 @@
 """pt_trace_closest_device_static -- the closest-hit query that allocates nothing (its
-scratch is a static device array) -- against pt_trace_closest, bit for bit, on two calls
-in a row, the second with a smaller input.  Collected last: a failure here must not
-hide the tests before it."""
+scratch is a static device array) -- against pt_trace_closest and against the CPU oracle,
+bit for bit, on two calls in a row, the second with a smaller input; that it allocates
+nothing is checked by the device's free memory around the calls and by issuing it while a
+HIP graph is being captured (where an allocation or a synchronising call fails the
+capture).  Collected last: a failure here must not hide the tests before it."""
 import ctypes as C
 
 import numpy as np
@@ -57,6 +59,58 @@ def test_static_trace_equals_pt_trace_closest(tmp_path):
     assert N.lib.pt_trace_closest_device_static(gpu._handle, C.c_void_p(16), N.PT_STATIC_TRACE_MAX_RAYS + 1, 0, C.c_void_p(16), None) == 1
     assert "PT_STATIC_TRACE_MAX_RAYS" in N.last_error()
     assert N.lib.pt_trace_closest_device_static(gpu._handle, C.c_void_p(16), 1, N.PT_FLAG_WAVEFRONT, C.c_void_p(16), None) == 1
+    gpu.close()
+
+
+def test_static_trace_against_the_oracle_allocates_nothing(tmp_path):
+    """The reason the entry point exists: no allocation, nothing that a graph capture refuses.  Two scene handles
+    of one device share the device's scratch array."""
+    import torch
+
+    from tests import oracle_binding as ob
+
+    d = str(tmp_path / "nested")
+    scene = P.Scene.load(d, H.write_nested_scene(d))
+    gpu = P.HipRenderer.init(scene, 0)
+    other = P.HipRenderer.init(P.Scene.load(H.SCENE_DATA, "./simple_scene.json"), 0)  # a second handle on the same device
+    osc = ob.load().scene(scene.desc_pointer)
+    first = H.random_rays(60_000, seed=31, origin_box=9.0, target_box=4.0)
+    second = H.random_rays(9_001, seed=32, origin_box=7.0, target_box=3.0)
+    want1 = osc.trace(first, accel=ob.ACCEL_LINEAR, math=ob.MATH_PORTABLE)
+    want2 = osc.trace(second, accel=ob.ACCEL_LINEAR, math=ob.MATH_PORTABLE)
+    # buffers first, then the calls between two readings of the device's free memory
+    d1 = torch.from_numpy(first).to("cuda:0")
+    d2 = torch.from_numpy(second).to("cuda:0")
+    h1 = torch.zeros(first.shape[0] * P.HIT_DTYPE.itemsize, dtype=torch.uint8, device="cuda:0")
+    h2 = torch.zeros(second.shape[0] * P.HIT_DTYPE.itemsize, dtype=torch.uint8, device="cuda:0")
+    h3 = torch.zeros_like(h2)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info(0)[0]
+    N.check(N.lib.pt_trace_closest_device_static(gpu._handle, d1.data_ptr(), first.shape[0], 0, h1.data_ptr(), None))
+    N.check(N.lib.pt_trace_closest_device_static(gpu._handle, d2.data_ptr(), second.shape[0], 0, h2.data_ptr(), None))
+    N.check(N.lib.pt_trace_closest_device_static(other._handle, d2.data_ptr(), second.shape[0], 0, h3.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(0)[0] == free_before, "the calls changed the device's free memory"
+    got1 = h1.cpu().numpy().view(P.HIT_DTYPE)
+    got2 = h2.cpu().numpy().view(P.HIT_DTYPE)
+    H.assert_hits_identical(got1, want1, "first call vs the oracle")
+    H.assert_hits_identical(got2, want2, "second, smaller call vs the oracle")
+    H.assert_hits_identical(h3.cpu().numpy().view(P.HIT_DTYPE), other.trace_closest(second), "second scene handle of the device")
+    assert got1["hit"].mean() > 0.3
+    # under graph capture: a hipMalloc, a hipFree or a synchronising call inside the entry point would fail the capture
+    h4 = torch.zeros_like(h2)
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=side):
+        N.check(N.lib.pt_trace_closest_device_static(gpu._handle, d2.data_ptr(), second.shape[0], 0, h4.data_ptr(),
+                                                     torch.cuda.current_stream().cuda_stream))
+    assert not h4.any(), "a captured launch does not run"
+    graph.replay()
+    torch.cuda.synchronize()
+    H.assert_hits_identical(h4.cpu().numpy().view(P.HIT_DTYPE), want2, "replayed from a captured graph vs the oracle")
+    osc.close()
+    other.close()
     gpu.close()
 
 

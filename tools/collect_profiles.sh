@@ -8,6 +8,8 @@
 #   rR_pmc_fetch.csv / rR_pmc_write.csv    FETCH_SIZE and WRITE_SIZE per launch (separate passes), dragon frame
 #   hbm_traffic.json                       HBM-side bytes per search_kernel launch, dragon frame
 #   rR_sq_counters.txt, sq_counters.json   SQ counters of the trace kernels, dragon frame
+#   rR_search_issue_mix.txt                the kernels' vector instructions by issue class (tools/issue_mix.py)
+# Every .json carries kernel_fingerprint: the device code the counters were taken with.
 #   rR_pmc_*_flattened.csv, hbm_traffic_flattened.json, rR_flattened_kernel_stats.csv   the 2.1e7-triangle flattened scene
 set -e
 R=${1:-2}
@@ -23,9 +25,14 @@ if [ "$2" = "summarize" ]; then
   python3 tools/summarize_sq.py $OUT/sq $R > /dev/null
   cp $FL/trace/*/*kernel_stats.csv profiles/r${R}_flattened_kernel_stats.csv
   python3 tools/summarize_traffic.py $FL $R flattened
+  cp $OUT/issue_mix.txt profiles/r${R}_search_issue_mix.txt
   exit 0
 fi
 mkdir -p $OUT $FL
+# which kernels the counters below belong to: bench.py replays them only into runs of the same device code
+python3 -c "from pathtracing_amd import _native as N; print(N.kernel_fingerprint())" | tee $OUT/kernel_fingerprint.txt > $FL/kernel_fingerprint.txt
+python3 tools/issue_mix.py --json > $OUT/issue_mix.json
+python3 tools/issue_mix.py > $OUT/issue_mix.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-hbm-regime > $OUT/trace.log 2>&1
 export PATHTRACING_AMD_STREAMS=1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_one -- python3 bench.py --no-cpu-baseline --no-hbm-regime > $OUT/trace_one.log 2>&1

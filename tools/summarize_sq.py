@@ -35,6 +35,22 @@ with open(f"profiles/r{rnd}_sq_counters.txt", "w") as f:
                       "active_lane_share": agg[k]["SQ_THREAD_CYCLES_VALU"] / (64.0 * valu) if valu else None,
                       "salu_insts_per_launch": agg[k]["SQ_INSTS_SALU"] / n, "vmem_rd_insts_per_launch": agg[k]["SQ_INSTS_VMEM_RD"] / n,
                       "wait_any_share_of_wave_cycles": agg[k]["SQ_WAIT_ANY"] / agg[k]["SQ_WAVE_CYCLES"] if agg[k]["SQ_WAVE_CYCLES"] else None}
+import os  # noqa: E402
+
+up = os.path.dirname(d.rstrip("/"))
+try:
+    out["kernel_fingerprint"] = open(f"{up}/kernel_fingerprint.txt").read().strip()  # device code the pass ran
+except OSError:
+    out["kernel_fingerprint"] = None
+try:
+    # static share of each kernel's vector instructions in the slow issue class (tools/issue_mix.py, same library)
+    for name, rec in json.load(open(f"{up}/issue_mix.json")).items():
+        for k in KERNELS:
+            if k in name and k in out:
+                out[k]["slow_class_share"] = rec["slow_class_share"]
+                out[k]["mean_issue_cycles"] = rec["mean_issue_cycles"]
+except (OSError, ValueError):
+    pass
 out["round"] = int(rnd)
 out["workload"] = "dragon stand-in 1920x1080 64spp depth 8, one render"
 json.dump(out, open("profiles/sq_counters.json", "w"), indent=1)

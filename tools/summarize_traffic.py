@@ -54,8 +54,13 @@ else:
     note = ("FETCH_SIZE is doubled as prescribed for gfx950 (128-B requests tallied at 64 B); the factor is calibrated "
             "for wide coalesced reads, the 64-B node and 48-B triangle records read here are uncalibrated, so the true "
             "figure lies between raw+write and 2*raw+write.  The counter includes Infinity-Cache hits.")
+try:
+    fingerprint = open(f"{d}/kernel_fingerprint.txt").read().strip()
+except OSError:
+    fingerprint = None
 json.dump({
     "round": int(rnd),
+    "kernel_fingerprint": fingerprint,  # device code the passes ran (pathtracing_amd._native.kernel_fingerprint)
     "command": f"rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- {command}",
     "kernel": "ptk::" + KERNEL,
     "workload": workload,
