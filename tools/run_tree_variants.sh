@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools/run_tree_variants.sh [--hbm] "NAME=VALUE ..." ...: bench.py once per setting of the tree builder
-# (PATHTRACING_AMD_BVH_<NAME>, host/bvh.cpp: default_bvh_tuning), one line of its search-kernel record each.
+# (PATHTRACING_AMD_BVH_<NAME>, host/bvh.cpp: default_bvh_tuning; a NAME that starts with PATHTRACING_AMD_ is taken as
+# it stands, for the library's other knobs), one line of its search-kernel record each.
 # With --hbm the flattened 2.1e7-triangle scene's record is kept beside the frame's.
 mkdir -p gpurun_out
 hbm=--no-hbm-regime
@@ -9,7 +10,7 @@ i=0
 for cfg in "$@"; do
   i=$((i+1))
   envs=()
-  for kv in $cfg; do envs+=("PATHTRACING_AMD_BVH_$kv"); done
+  for kv in $cfg; do case $kv in PATHTRACING_AMD_*) envs+=("$kv");; *) envs+=("PATHTRACING_AMD_BVH_$kv");; esac; done
   env "${envs[@]}" timeout -k 10 400 python3 bench.py --no-cpu-baseline $hbm --steps 3 --warmup 1 > gpurun_out/tree_$i.json 2> gpurun_out/tree_$i.err || { echo "FAILED $cfg"; tail -5 gpurun_out/tree_$i.err; exit 1; }
   python3 - "$cfg" gpurun_out/tree_$i.json <<'PY' | tee -a gpurun_out/tree_variants.txt
 import json, sys
