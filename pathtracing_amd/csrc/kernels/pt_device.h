@@ -664,6 +664,21 @@ __device__ __forceinline__ uint32_t run_next(const DRun& run, const Ray& world, 
     return kRunNone;
 }
 
+// One node of the box tree: the child it holds if the ray pierces it and it is a leaf, else kRunNone;
+// the cursor moves on either way (callers loop while run_live).
+__device__ __forceinline__ bool run_live(const DRun& run, const RunCursor& c) { return c.i < run.tlas_count; }
+__device__ __forceinline__ uint32_t run_step(const DRun& run, const Ray& world, RunCursor& c) {
+    GlobalF4Ptr nodes = global_f4(run.tlas);
+    float4 a = nodes[2 * (int)c.i], b = nodes[2 * (int)c.i + 1];
+    float bmin[3] = {a.x, a.y, a.z}, bmax[3] = {b.x, b.y, b.z};
+    const uint32_t skip = __float_as_uint(a.w), child = __float_as_uint(b.w);
+    float entry;
+    const bool pierced = box_test(bmin, bmax, world.source, c.inv, c.limit, &entry);
+    const bool leaf = child != kTlasInner;
+    c.i = (pierced && !leaf) ? c.i + 1u : skip;
+    return (pierced && leaf) ? child : kRunNone;
+}
+
 // A child's table entry: ids, and the ray of `world` in the child's space
 // (Ray::apply_transform, ray.rs:21-37, on the packed copy of the transform node).
 struct RunChildIds {

@@ -148,41 +148,82 @@ __device__ __forceinline__ uint32_t list_searches(const DScene& scene, const Sea
     // The instance run: one job per child whose world-space box the ray pierces and whose mesh
     // bounds the ray reaches in the child's space.  A ray's jobs are chained through job_c.w.
     // When the region's job list is full the ray is marked and searched while walking instead.
+    //
+    // Rays pierce different numbers of boxes, and taking a ray into a child's space is the expensive part
+    // (~190 instructions), so the two are separated: first every lane walks the box tree and puts its
+    // (lane, child) pairs into the wave's list in LDS; then the pairs are worked off 64 at a time, every lane
+    // busy, each lane fetching the ray of the pair's lane with cross-lane reads.  A ray's chain is linked by
+    // an exchange on its head in LDS, so its jobs are chained in no particular order (walk_run takes the
+    // minimum over the chain).
+    constexpr uint32_t kPairs = 512, kLaneShift = 26;
+    __shared__ uint32_t run_pairs[kBlock / 64][kPairs];
+    __shared__ uint32_t run_heads[kBlock / 64][64];
+    const uint32_t lane = (uint32_t)__popcll(lane_lt), w = threadIdx.x >> 6;
     RunCursor cursor;
     run_begin(scene.run, world, queued, cursor);
-    uint32_t head = kRunNone;
-    for (;;) {
-        const uint32_t k = run_next(scene.run, world, cursor);
-        if (__ballot(k != kRunNone) == 0ull) break;
-        bool need = false;
-        Ray ray = world;
-        uint32_t mesh_id = 0u;
+    run_heads[w][lane] = kRunNone;
+    uint32_t n_pairs = 0u;  // wave-uniform
+    bool pierces = false;   // this lane's ray has a pair
+    bool overflow = scene.run.child_count > (1u << kLaneShift); // wave-uniform: the region's list cannot take the chunk's jobs
+    for (bool more = true; more && !overflow;) {
+        // one node of the box tree per lane and pass, every lane at its own place in the tree
+        const bool live = run_live(scene.run, cursor);
+        const uint32_t k = live ? run_step(scene.run, world, cursor) : kRunNone;
+        more = __ballot(live) != 0ull;
+        const unsigned long long found = __ballot(k != kRunNone);
         if (k != kRunNone) {
-            const RunChildIds ids = run_child_ids(scene.run, k);
-            mesh_id = ids.mesh_id;
-            ray = run_child_ray(scene.run, k, ids, world);
-            need = trav_reaches(scene.meshes[mesh_id], ray);
+            run_pairs[w][n_pairs + (uint32_t)__popcll(found & lane_lt)] = (lane << kLaneShift) | k;
+            pierces = true;
         }
-        const unsigned long long mask = __ballot(need);
-        const uint32_t wanted = (uint32_t)__popcll(mask);
-        if (run_used + wanted > sl.run_cap) { // wave-uniform; the other mesh nodes' share of the list stays theirs
-            if (need) {
-                head = kRunInPlace;
-                cursor.i = scene.run.tlas_count;
+        n_pairs += (uint32_t)__popcll(found);
+        if (more && n_pairs + 64u <= kPairs) continue; // room for another pass
+        // work the list off: every lane takes a pair
+        for (uint32_t first = 0u; first < n_pairs && !overflow; first += 64u) {
+            const bool have = first + lane < n_pairs;
+            const uint32_t pair = have ? run_pairs[w][first + lane] : 0u;
+            const uint32_t from = pair >> kLaneShift, child = pair & ((1u << kLaneShift) - 1u);
+            Ray theirs;
+            theirs.source = mk3(__shfl(world.source.x, (int)from), __shfl(world.source.y, (int)from), __shfl(world.source.z, (int)from));
+            theirs.direction = mk3(__shfl(world.direction.x, (int)from), __shfl(world.direction.y, (int)from),
+                                   __shfl(world.direction.z, (int)from));
+            theirs.min = __shfl(world.min, (int)from);
+            theirs.max = __shfl(world.max, (int)from);
+            const uint32_t their_item = (uint32_t)__shfl((int)item, (int)from);
+            bool need = false;
+            Ray ray = theirs;
+            uint32_t mesh_id = 0u;
+            if (have) {
+                const RunChildIds ids = run_child_ids(scene.run, child);
+                mesh_id = ids.mesh_id;
+                ray = run_child_ray(scene.run, child, ids, theirs);
+                need = trav_reaches(scene.meshes[mesh_id], ray);
             }
-            continue;
+            const unsigned long long mask = __ballot(need);
+            const uint32_t wanted = (uint32_t)__popcll(mask);
+            if (run_used + wanted > sl.run_cap) { // the other mesh nodes' share of the list stays theirs
+                overflow = true;
+                break;
+            }
+            if (need) {
+                const uint32_t at = job_pos + (uint32_t)__popcll(mask & lane_lt);
+                const size_t j = job_base + at;
+                const uint32_t previous = atomicExch(&run_heads[w][from], at);
+                sl.job_a[j] = make_float4(ray.source.x, ray.source.y, ray.source.z, ray.min);
+                sl.job_b[j] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, ray.max);
+                sl.job_c[j] = make_float4(__uint_as_float(their_item), __uint_as_float(mesh_id),
+                                          __uint_as_float(kRunJobFlag | child), __uint_as_float(previous));
+            }
+            job_pos += wanted;
+            run_used += wanted;
         }
-        if (need) {
-            const uint32_t at = job_pos + (uint32_t)__popcll(mask & lane_lt);
-            const size_t j = job_base + at;
-            sl.job_a[j] = make_float4(ray.source.x, ray.source.y, ray.source.z, ray.min);
-            sl.job_b[j] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, ray.max);
-            sl.job_c[j] = make_float4(__uint_as_float(item), __uint_as_float(mesh_id), __uint_as_float(kRunJobFlag | k),
-                                      __uint_as_float(head));
-            head = at;
-        }
-        job_pos += wanted;
-        run_used += wanted;
+        n_pairs = 0u;
+    }
+    uint32_t head = run_heads[w][lane];
+    if (overflow) {
+        // the rays of this chunk that pierce a box at all are searched while walking (jobs already listed for
+        // them are searched for nothing); a lane that has not met its first box yet looks for it now
+        if (!pierces) pierces = run_next(scene.run, world, cursor) != kRunNone;
+        head = pierces ? kRunInPlace : kRunNone;
     }
     if (queued) sl.run_head[(size_t)r * cap + item] = head;
     return listed;

@@ -135,3 +135,44 @@ def test_failed_write_back_leaves_a_usable_description(tmp_path):
     assert scene.cache_trees(str(d)) == 1 and scene.cache_trees(str(d)) == 0
     assert S.validate_tree(scene.desc.meshes[1], (d / "missing_dir" / "b.tree").read_bytes())
     scene.close()
+
+
+def _tree_shape(blob):
+    """(node count, leaf sizes) of a .tree blob: header, then 64-byte binary nodes whose last four dwords are
+    left, right, pad, pad (negative reference = leaf: ~ref = first << 3 | count - 1)."""
+    node_count = struct.unpack_from("<Q", blob, 24)[0]
+    header = len(blob) - node_count * 64 - struct.unpack_from("<Q", blob, 16)[0] * 4
+    sizes = []
+    for i in range(node_count):
+        left, right = struct.unpack_from("<ii", blob, header + 64 * i + 48)
+        for ref in (left, right):
+            if ref < 0:
+                sizes.append(((~ref) & 7) + 1)
+    return node_count, np.array(sizes)
+
+
+@pytest.mark.parametrize("knobs", [
+    {},                                                        # the defaults: leaves chosen by cost
+    {"PATHTRACING_AMD_BVH_COLLAPSE": "0"},                      # every range of <= 4 triangles a leaf
+    {"PATHTRACING_AMD_BVH_TRI_COST": "2.5"},                    # nearly every triangle its own leaf
+    {"PATHTRACING_AMD_BVH_TRI_COST": "0.05", "PATHTRACING_AMD_BVH_MAX_LEAF": "8"},
+    {"PATHTRACING_AMD_BVH_BINS": "4", "PATHTRACING_AMD_BVH_SWEEP": "0"},
+    {"PATHTRACING_AMD_BVH_SWEEP": "256", "PATHTRACING_AMD_BVH_ROTATE": "3"},
+])
+def test_every_setting_of_the_builder_gives_a_valid_tree(knot, monkeypatch, knobs):
+    """The builder's knobs (host/bvh.cpp: default_bvh_tuning) change the shape of the tree, never its validity:
+    every triangle in exactly one leaf, every box enclosing what lies below it (pt_tree_validate), same bytes
+    when built twice."""
+    mesh = knot.desc.meshes[0]
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    blob = S.build_tree(mesh)
+    assert S.validate_tree(mesh, blob) and S.build_tree(mesh) == blob
+    nodes, sizes = _tree_shape(blob)
+    assert sizes.sum() == mesh.triangle_count and sizes.size == nodes + 1
+    limit = int(knobs.get("PATHTRACING_AMD_BVH_MAX_LEAF", 4))
+    assert sizes.max() <= limit
+    if knobs.get("PATHTRACING_AMD_BVH_TRI_COST") == "2.5":
+        assert sizes.mean() < 1.3
+    if knobs.get("PATHTRACING_AMD_BVH_MAX_LEAF") == "8":
+        assert sizes.max() > 4 and sizes.mean() > 3.0
