@@ -19,7 +19,7 @@ FL=gpurun_out/flattened_r$R
 if [ "$2" = "summarize" ]; then
   mkdir -p profiles
   cp $OUT/trace/*/*kernel_stats.csv profiles/r${R}_bench_kernel_stats.csv
-  tail -1 $OUT/trace.log > profiles/r${R}_bench_line_under_rocprof.json
+  grep '^{"metric"' $OUT/trace.log | tail -1 > profiles/r${R}_bench_line_under_rocprof.json
   cp $OUT/trace_one/*/*kernel_stats.csv profiles/r${R}_bench_kernel_stats_one_batch.csv
   python3 tools/summarize_traffic.py $OUT $R
   python3 tools/summarize_sq.py $OUT/sq $R > /dev/null

@@ -126,7 +126,7 @@ def main():
     if as_json:
         print(json.dumps(out))
         return
-    print(f"{lib}\nissue classes: fast {FAST_CYCLES} cycles, slow {SLOW_CYCLES} cycles per wave64 instruction (profiles/r3_valu_issue.txt)")
+    print(f"{os.path.basename(lib)}\nissue classes: fast {FAST_CYCLES} cycles, slow {SLOW_CYCLES} cycles per wave64 instruction (profiles/r3_valu_issue.txt)")
     for pretty, rec in out.items():
         def show(tag, r):
             print(f"  {tag:24s} {r['valu']:5d} vector instructions: {r['fast']:5d} fast, {r['slow']:5d} slow "
