@@ -326,3 +326,45 @@ def test_listen_mode_of_the_native_example(tmp_path):
     finally:
         if proc.poll() is None:
             proc.kill()
+
+
+def test_blocking_serve_until_the_flag_is_set(tmp_path):
+    """pt_worker_serve: start_ws as one call that returns when *stop_flag becomes non-zero."""
+    import ctypes as C
+    import threading
+
+    from pathtracing_amd import _native as N
+
+    def free_port(kind):
+        s = socket.socket(socket.AF_INET, kind)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        return port
+
+    ws, udp = free_port(socket.SOCK_STREAM), free_port(socket.SOCK_DGRAM)
+    worker = F.WorkerFrontEnd(str(tmp_path), 0)
+    flag = C.c_int32(0)
+    status = []
+    t = threading.Thread(target=lambda: status.append(N.lib.pt_worker_serve(worker._handle, b"127.0.0.1", ws, udp, C.byref(flag))))
+    t.start()
+    s = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    s.settimeout(0.5)
+    reply = None
+    for _ in range(20):  # until the sockets are up
+        try:
+            s.sendto(b"", ("127.0.0.1", udp))
+            reply = s.recvfrom(16)[0]
+            break
+        except (socket.timeout, ConnectionError):
+            time.sleep(0.1)
+    s.close()
+    assert reply is not None and F.discovery_response_port(reply) == ws
+    c = WsClient(ws)
+    assert c.status_line.startswith(b"HTTP/1.1 101")
+    flag.value = 1
+    t.join(5)
+    assert not t.is_alive() and status == [0]
+    assert c.closed_by_peer()
+    c.close()
+    worker.close()
