@@ -313,6 +313,18 @@ __device__ __forceinline__ GlobalF4Ptr global_f4(const void* p) {
     return g;
 }
 
+// A load that writes LDS directly (no register holds the data): every lane names its own 16 (4) bytes of global
+// memory, and the wave's 64 pieces land next to each other from `wave_dst`, lane 0's first.  The load is counted by
+// vmcnt like any other; the wave that issued it may read the LDS copy after waiting for it.
+__device__ __forceinline__ void lds_dma16(const void* src, void* wave_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(unsigned long long)src,
+                                     (__attribute__((address_space(3))) void*)wave_dst, 16, 0, 0);
+}
+__device__ __forceinline__ void lds_dma4(const void* src, void* wave_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(unsigned long long)src,
+                                     (__attribute__((address_space(3))) void*)wave_dst, 4, 0, 0);
+}
+
 __device__ __forceinline__ LeafTri load_tri(const LeafTri* p) {
     GlobalF4Ptr q = global_f4(p);
     float4 a = q[0], b = q[1], c = q[2];
@@ -595,6 +607,27 @@ __device__ __forceinline__ void walk_begin(WalkState& w, const Ray& ray) {
 typedef const __attribute__((address_space(4))) DNode* ConstNodePtr;
 __device__ __forceinline__ ConstNodePtr const_nodes(const DScene& sc) {
     return (ConstNodePtr)(unsigned long long)(sc.nodes);
+}
+// The description of mesh `id`, the same for every lane (a mesh node's, a search target's): read with scalar
+// loads like the node array, so a wave does not wait a trip to memory through the vector path for a
+// pointer it shares.  Only the fields the caller goes on to use are loaded.
+__device__ __forceinline__ DMesh uniform_mesh(const DScene& sc, uint32_t id) {
+    typedef const __attribute__((address_space(4))) DMesh* ConstMeshPtr;
+    ConstMeshPtr m = (ConstMeshPtr)(unsigned long long)(sc.meshes) + id;
+    DMesh d;
+    d.nodes = m->nodes;
+    d.tris = m->tris;
+    d.tris_orig = m->tris_orig;
+    d.shade = m->shade;
+    d.tri_count = m->tri_count;
+    d.node_count = m->node_count;
+    d.root_ref = m->root_ref;
+    d.pad = 0u;
+    for (int k = 0; k < 3; k++) {
+        d.bmin[k] = m->bmin[k];
+        d.bmax[k] = m->bmax[k];
+    }
+    return d;
 }
 __device__ __forceinline__ V3 cv3(const __attribute__((address_space(4))) V3& v) { return mk3(v.x, v.y, v.z); }
 
@@ -970,7 +1003,7 @@ __device__ __forceinline__ int walk(const DScene& sc, WalkState& w, Hit& cur, bo
 template <bool kRun>
 __device__ __forceinline__ void walk_flat(const DScene& sc, const Ray& world, float4* const* res, size_t index,
                                           uint32_t deferred, uint32_t listed, uint32_t live_meshes, const RunLookup* run,
-                                          TravStack& st, Hit* out, bool all_uv = false) {
+                                          TravStack& st, Hit* out, bool all_uv = false, const float4* first_res = nullptr) {
     ConstNodePtr nodes = const_nodes(sc);
     Hit best;
     best.hit = 0u;
@@ -1021,11 +1054,11 @@ __device__ __forceinline__ void walk_flat(const DScene& sc, const Ray& world, fl
                     DNode nd;
                     nd.material_id = nodes[j].material_id;
                     nd.mesh_id = nodes[j].mesh_id;
-                    const DMesh& mesh = sc.meshes[nd.mesh_id];
+                    const DMesh mesh = uniform_mesh(sc, nd.mesh_id);
                     TravState ts;
                     if (m < deferred) {
                         float4 r = make_float4(f32_inf(), __uint_as_float(0u), __uint_as_float(0u), __uint_as_float(0xFFFFFFFFu));
-                        if ((listed >> m) & 1u) r = res[m][index];
+                        if ((listed >> m) & 1u) r = (first_res != nullptr && m == 0u) ? *first_res : res[m][index];
                         ts.tbest = r.x;
                         ts.found = __float_as_uint(r.y);
                         ts.best_slot = __float_as_uint(r.z);
@@ -1109,8 +1142,9 @@ __device__ __forceinline__ void scene_trace(const DScene& sc, Ray ray, bool brut
 
 // ------------------------------------------------------------------ materials
 // material_input/mod.rs:49-56, texture.rs:53-66, image.rs:39-46
-__device__ __forceinline__ V3 sample_color(const DMaterial& m, V2 uv) {
-    if (!m.color_is_texture) return m.color;
+// In two steps, so that a caller can start the fetch of the texel, do other work, and take the colour later.
+__device__ __forceinline__ uint32_t sample_color_fetch(const DMaterial& m, V2 uv) {
+    if (!m.color_is_texture) return 0u;
     if (m.uv_mode == 0u) uv = mk2(clamp_f(uv.x, 0.0f, 1.0f), clamp_f(uv.y, 0.0f, 1.0f));
     else uv = mk2(uv.x - floorf(uv.x), uv.y - floorf(uv.y));
     uv.y = 1.0f - uv.y;
@@ -1118,10 +1152,14 @@ __device__ __forceinline__ V3 sample_color(const DMaterial& m, V2 uv) {
     uint32_t x = f32_as_u32(coords.x), y = f32_as_u32(coords.y);
     if (x >= m.tex_w) x = m.tex_w - 1u;
     if (y >= m.tex_h) y = m.tex_h - 1u;
-    uint32_t texel = ((const __attribute__((address_space(1))) uint32_t*)(unsigned long long)m.texels)[(size_t)y * m.tex_w + x];
+    return ((const __attribute__((address_space(1))) uint32_t*)(unsigned long long)m.texels)[(size_t)y * m.tex_w + x];
+}
+__device__ __forceinline__ V3 sample_color_finish(const DMaterial& m, uint32_t texel) {
+    if (!m.color_is_texture) return m.color;
     return mk3((float)(texel & 0xFFu) / 256.0f, (float)((texel >> 8) & 0xFFu) / 256.0f,
                (float)((texel >> 16) & 0xFFu) / 256.0f);
 }
+__device__ __forceinline__ V3 sample_color(const DMaterial& m, V2 uv) { return sample_color_finish(m, sample_color_fetch(m, uv)); }
 
 // math/src/lib.rs:272-280
 __device__ __forceinline__ V3 random_on_unit_sphere(float rand_0, float rand_1) {
@@ -1184,6 +1222,9 @@ __device__ __forceinline__ bool material_get_color(const DMaterial& m, V3 dir, c
         kind = rng.gen_bool_half() ? kPbrCosine : kPbrUniform;
     }
 
+    // the texel of a diffuse bounce is on its way while the sphere point is worked out
+    uint32_t texel = 0u;
+    if (kind == kDiffuse) texel = sample_color_fetch(m, tr.uv);
     V3 sphere_point = mk3(0, 0, 0);
     if (kind == kDiffuse || kind == kPbrUniform) sphere_point = random_on_unit_sphere(u0, u1);
 
@@ -1222,7 +1263,7 @@ __device__ __forceinline__ bool material_get_color(const DMaterial& m, V3 dir, c
     if (kind == kDiffuse) {
         V3 new_direction = sphere_point;
         if (dot(new_direction, tr.normal) < 0.0f) new_direction = mk3(0, 0, 0) - new_direction;
-        *a = sample_color(m, tr.uv);
+        *a = sample_color_finish(m, texel);
         *out_dir = new_direction;
         return false;
     }

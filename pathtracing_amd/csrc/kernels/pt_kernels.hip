@@ -35,16 +35,49 @@ __device__ __forceinline__ void path_slot_to_pixel(const BatchGeometry& g, uint3
     *y = g.y0 + ly;
 }
 
+// Division of path ids by the batch's (wave-uniform) block and slot counts, once per ray and bounce: the
+// quotient estimate mulhi(n, floor(2^32 / d)) is the quotient or one less (n * floor(2^32 / d) / 2^32 lies in
+// (n / d - 1, n / d]), so one correction makes it exact; the reciprocal comes from the host, in a scalar register.
+struct Divisor {
+    uint32_t d, inv;
+};
+inline Divisor make_divisor(uint32_t d) {
+    Divisor v;
+    v.d = d;
+    v.inv = d <= 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / d);
+    return v;
+}
+__device__ __forceinline__ uint32_t divide(uint32_t n, Divisor v, uint32_t* remainder) {
+    uint32_t q = __umulhi(n, v.inv);
+    uint32_t r = n - q * v.d;
+    if (r >= v.d) {
+        q++;
+        r -= v.d;
+    }
+    *remainder = r;
+    return q;
+}
+
 struct RenderParams {
     DScene scene;
     DCamera cam;
     BatchGeometry geo;
+    Divisor by_npp, by_nbx; // geo.npp, geo.nbx
     uint64_t seed;
     uint64_t sample_first;
     uint32_t sample_count;
     uint32_t trace_depth;
     uint32_t brute;
 };
+
+// Sample (within the batch) and pixel of a path id.
+__device__ __forceinline__ void path_to_pixel(const RenderParams& p, uint32_t path, uint32_t* s_local, uint32_t* x, uint32_t* y) {
+    uint32_t q, bx;
+    *s_local = divide(path, p.by_npp, &q);
+    const uint32_t by = divide(q >> 6, p.by_nbx, &bx), within = q & 63u;
+    *x = p.geo.x0 + bx * 8u + (within & 7u);
+    *y = p.geo.y0 + by * 8u + (within >> 3);
+}
 
 __device__ __forceinline__ TravStack make_stack(int32_t* lds_stack, uint32_t* spill, uint32_t spill_threads) {
     TravStack st;
@@ -129,10 +162,11 @@ __device__ __forceinline__ uint32_t list_searches(const DScene& scene, const Sea
         bool need = false;
         Ray ray = world;
         const uint32_t mesh_id = targets[m].mesh_id;
+        const DMesh mesh = uniform_mesh(scene, mesh_id); // asked for before the transforms, used after them
         if (queued) {
             const uint32_t chain_len = targets[m].chain_len;
             for (uint32_t c = 0; c < chain_len; c++) ray = transform_ray_c(nodes[targets[m].chain[c]], ray);
-            need = trav_reaches(scene.meshes[mesh_id], ray);
+            need = trav_reaches(mesh, ray);
             if (need) listed |= 1u << m;
         }
         const unsigned long long mask = __ballot(need);
@@ -567,10 +601,8 @@ bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList sl, u
                     cur.normal = mk3(hb.x, hb.y, hb.z);
                     cur.uv = mk2(hb.w, rec.hc);
                     V3 mult = mk3(rc.x, rc.y, rc.z);
-                    uint32_t s_local = path / p.geo.npp, q = path % p.geo.npp;
-                    uint32_t x, y;
-                    bool valid;
-                    path_slot_to_pixel(p.geo, q, &x, &y, &valid);
+                    uint32_t s_local, x, y;
+                    path_to_pixel(p, path, &s_local, &x, &y);
                     Rng rng;
                     rng.key = stream_key(p.seed, stream_id(p.sample_first + s_local, (uint64_t)x + (uint64_t)y * p.cam.width));
                     rng.counter = rng_counter;
@@ -625,14 +657,18 @@ bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList sl, u
 // Scenes with a flat root and no instance run: walk_flat and the bounce in one kernel, the hit
 // staying in registers (the two kernels hand each other 36 bytes per ray through memory, and the
 // bounce is bound by its memory traffic).  Four waves per SIMD: built without the SLP vectoriser (its
-// packed two-float operations want aligned register pairs and the moves to form them) the kernel needs
-// 135 registers, and held to 128 it spills one; fetching the next chunk's records ahead, as
-// bounce_kernel does, costs more in spills than it hides here.  Scenes with an instance run keep the two kernels: the
+// packed two-float operations want aligned register pairs and the moves to form them) the kernel fits
+// 128 registers.  With four waves there is little to cover a trip to memory with, so the kernel keeps such
+// trips off its critical path: the next chunk's records come into LDS by direct loads while this chunk is
+// worked on (registers could not hold them), what all lanes share (mesh descriptions, scene nodes) comes by
+// scalar loads, the materials are read from LDS, and the texel of a diffuse bounce is fetched before the
+// arithmetic that does not need it.  Scenes with an instance run keep the two kernels: the
 // walk reads the segment's job list while the bounce overwrites it with the next segment's.
 // kFull: as in walk_kernel.
 #ifndef PT_WALK_BOUNCE_OCCUPANCY
 #define PT_WALK_BOUNCE_OCCUPANCY 4
 #endif
+constexpr uint32_t kWalkBounceMaterials = 32; // materials a scene may have to take this kernel
 template <bool kFull = false>
 __global__ void __launch_bounds__(kBlock, PT_WALK_BOUNCE_OCCUPANCY)
 walk_bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList sl, uint32_t cap, uint32_t regions,
@@ -646,19 +682,37 @@ walk_bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList 
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     TravStack st = make_stack(lds_stack, spill, spill_threads);
     unsigned long long traced = 0, jobs_listed = 0;
-    constexpr uint32_t kLdsMaterials = 32;
-    __shared__ DMaterial lds_materials[kLdsMaterials];
-    const uint32_t n_lds = p.scene.material_count < kLdsMaterials ? p.scene.material_count : kLdsMaterials;
+    // every material of the scene is read from a copy in LDS (the launcher keeps scenes with more than
+    // kWalkBounceMaterials on the two-kernel route): LDS reads, not flat ones that could be either
+    __shared__ DMaterial lds_materials[kWalkBounceMaterials];
+    const uint32_t n_lds = p.scene.material_count < kWalkBounceMaterials ? p.scene.material_count : kWalkBounceMaterials;
     for (uint32_t i = threadIdx.x; i < n_lds * (uint32_t)(sizeof(DMaterial) / 4); i += kBlock)
         reinterpret_cast<uint32_t*>(lds_materials)[i] = reinterpret_cast<const uint32_t*>(p.scene.materials)[i];
     __syncthreads();
     const uint32_t searched = p.scene.target_count < (uint32_t)kMaxDeferred ? p.scene.target_count : (uint32_t)kMaxDeferred;
+    // The records of the next chunk (ray, listed searches, the first mesh node's result) are brought into LDS
+    // by loads that write LDS directly while this chunk is worked on: no registers are held for them.
+    __shared__ float4 ahead[kBlock / 64][4][64];
+    __shared__ uint32_t ahead_listed[kBlock / 64][64];
+    const uint32_t w = threadIdx.x >> 6;
 
     for (uint32_t r = wave; r < regions; r += waves) {
         const size_t base = (size_t)r * cap;
         const uint32_t n_items = b.ray_counts[r];
         traced += n_items;
         uint32_t out_pos = 0u, job_pos = 0u, run_used = 0u;
+        auto fetch_ahead = [&](uint32_t first) { // n_items != 0; lanes past the end fetch the last record again
+            const uint32_t it = first + lane < n_items ? first + lane : n_items - 1u;
+            const size_t at = base + it;
+            lds_dma16(b.ray_a + at, &ahead[w][0][0]);
+            lds_dma16(b.ray_b + at, &ahead[w][1][0]);
+            lds_dma16(b.ray_c + at, &ahead[w][2][0]);
+            if (searched) {
+                lds_dma4(b.listed + at, &ahead_listed[w][0]);
+                lds_dma16(b.res[0] + at, &ahead[w][3][0]);
+            }
+        };
+        if (n_items) fetch_ahead(0u);
         for (uint32_t first = 0; first < n_items; first += 64u) {
             const uint32_t item = first + lane;
             const bool active = item < n_items;
@@ -669,26 +723,31 @@ walk_bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList 
             // ---- hierarchy.trace_ray (work_group.rs:30)
             float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
             uint32_t listed = 0u;
-            if (active) {
-                ra = b.ray_a[base + item];
-                rb = b.ray_b[base + item];
-                rc = b.ray_c[base + item];
-                if (searched) listed = b.listed[base + item];
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the records have landed
+            ra = ahead[w][0][lane];
+            rb = ahead[w][1][lane];
+            rc = ahead[w][2][lane];
+            if (searched) listed = active ? ahead_listed[w][lane] : 0u;
             uint32_t live = 0xFFFFFFFFu;
             for (uint32_t m = 0; m < searched; m++) {
                 uint32_t found = 0u;
-                if ((listed >> m) & 1u) found = __float_as_uint(b.res[m][base + item].y);
+                if ((listed >> m) & 1u) found = __float_as_uint(m == 0u ? ahead[w][3][lane].y : b.res[m][base + item].y);
                 if (__ballot(found != 0u) == 0ull) live &= ~(1u << m);
             }
+            Ray ray;
+            ray.source = mk3(ra.x, ra.y, ra.z);
+            ray.min = ra.w;
+            ray.direction = mk3(rb.x, rb.y, rb.z);
+            ray.max = kF32Max;
+            Hit cur;
+            cur.hit = 0u;
+            if (active)
+                walk_flat<false>(p.scene, ray, b.res, base + item, (uint32_t)kMaxDeferred, listed, live, nullptr, st, &cur, kFull,
+                                 &ahead[w][3][lane]);
+            // this chunk's copy has been read: the next chunk's records may overwrite it
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (first + 64u < n_items) fetch_ahead(first + 64u);
             if (active) {
-                Ray ray;
-                ray.source = mk3(ra.x, ra.y, ra.z);
-                ray.min = ra.w;
-                ray.direction = mk3(rb.x, rb.y, rb.z);
-                ray.max = kF32Max;
-                Hit cur;
-                walk_flat<false>(p.scene, ray, b.res, base + item, (uint32_t)kMaxDeferred, listed, live, nullptr, st, &cur, kFull);
                 // ---- the rest of the segment (work_group.rs:31-47)
                 path = __float_as_uint(rb.w);
                 if (kFull) full_hits[path] = to_pt_hit(cur);
@@ -697,15 +756,13 @@ walk_bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList 
                 bool finished = true;
                 if (cur.hit) {
                     V3 mult = mk3(rc.x, rc.y, rc.z);
-                    uint32_t s_local = path / p.geo.npp, q = path % p.geo.npp;
-                    uint32_t x, y;
-                    bool valid;
-                    path_slot_to_pixel(p.geo, q, &x, &y, &valid);
+                    uint32_t s_local, x, y;
+                    path_to_pixel(p, path, &s_local, &x, &y);
                     Rng rng;
                     rng.key = stream_key(p.seed, stream_id(p.sample_first + s_local, (uint64_t)x + (uint64_t)y * p.cam.width));
                     rng.counter = rng_counter;
                     V3 av, dir;
-                    const DMaterial* material = cur.material_id < n_lds ? &lds_materials[cur.material_id] : &p.scene.materials[cur.material_id];
+                    const DMaterial* material = &lds_materials[cur.material_id < n_lds ? cur.material_id : 0u];
                     bool is_color = material_get_color(*material, ray.direction, cur, rng, &av, &dir);
                     rng_counter = rng.counter;
                     if (is_color) {
@@ -1219,6 +1276,8 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
     p.scene = scene;
     p.cam = cam;
     p.geo = geo;
+    p.by_npp = make_divisor(geo.npp);
+    p.by_nbx = make_divisor(geo.nbx);
     p.seed = seed;
     p.sample_first = sample_first;
     p.sample_count = sample_count;
@@ -1260,7 +1319,7 @@ hipError_t render_batch(const DScene& scene, const DCamera& cam, const BatchGeom
         // one loop over the root's children where the scene has that shape (not in the linear-scan mode,
         // whose searches happen inside the general walk)
         const bool flat = scene.flat_root != 0u && !brute;
-        if (flat && !with_run) {
+        if (flat && !with_run && scene.material_count <= kWalkBounceMaterials) {
             walk_bounce_kernel<false><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, d, b, sl, cap, regions, ws.contrib, rt,
                                                                                    ws.spill, spill_threads);
             continue;
@@ -1307,6 +1366,8 @@ hipError_t trace_closest_wavefront(const DScene& scene, const std::vector<MeshTa
     p.geo.nbx = 1u;
     p.geo.nby = 0x1FFFFFFFu;
     p.geo.npp = 0xFFFFFFFFu;
+    p.by_npp = make_divisor(p.geo.npp);
+    p.by_nbx = make_divisor(p.geo.nbx);
     p.sample_count = 1u;
     p.trace_depth = 1u;
     const uint32_t regions = pl.regions, spill_threads = pl.spill_threads;
@@ -1317,7 +1378,7 @@ hipError_t trace_closest_wavefront(const DScene& scene, const std::vector<MeshTa
     if (pl.searched || pl.run_slots) launch_search(scene, pl, stream);
     const bool flat = scene.flat_root != 0u;
     unsigned long long* rt = pl.totals;
-    if (flat && !with_run && !split) {
+    if (flat && !with_run && !split && scene.material_count <= kWalkBounceMaterials) {
         walk_bounce_kernel<true><<<ws.persistent_blocks, kBlock, 0, stream>>>(p, 0u, b, pl.sl, cap, regions, ws.contrib, rt,
                                                                               ws.spill, spill_threads, d_hits);
     } else if (with_run) {
