@@ -118,3 +118,39 @@ def test_random_materials_cameras_options(oracle, fuzz_root, seed):
     assert same.all(), f"seed {seed}: {np.count_nonzero(~same)} of {same.size} values differ, first at {np.argwhere(~same)[0]}"
     gpu.close()
     cpu.close()
+
+
+@pytest.mark.parametrize("n_materials", [32, 33, 48])
+def test_scenes_around_the_material_limit_of_the_fused_kernel(oracle, fuzz_root, n_materials):
+    """A flat scene takes walk_bounce_kernel (materials from its LDS copy) while it has at most 32 materials and the
+    walk and bounce kernels beyond: the same images as the oracle's on both sides of the limit, and through
+    pt_trace_closest's wavefront route."""
+    rnd = np.random.default_rng(77 + n_materials)
+    u = lambda lo, hi: float(rnd.uniform(lo, hi))  # noqa: E731
+    children = [{"type": "sphere", "center": [0.0, 7.0, 3.0], "radius": 3.0, "material": "./materials/mat0.json"}]
+    for k in range(n_materials - 1):
+        with open(os.path.join(fuzz_root, "materials", f"m{k}.json"), "w") as f:
+            json.dump(random_material(rnd), f)
+        children.append({"type": "sphere", "center": [u(-5, 5), u(-3, 3), u(-4, 2)], "radius": u(0.3, 0.9), "material": f"./materials/m{k}.json"})
+    children.append({"type": "transform", "matrix": H._trs(0.7, (0.8,) * 3, (0.5, -1.0, 0.0)),
+                     "child": {"type": "mesh", "path": "./gem.obj", "material": "./materials/m0.json"}})
+    children.append({"type": "plane", "point": [0.0, -3.0, 0.0], "normal": [0.0, 1.0, 0.0], "tangent": [0.0, 0.0, -1.0],
+                     "bitangent": [1.0, 0.0, 0.0], "material": "./materials/m1.json"})
+    with open(os.path.join(fuzz_root, "many.json"), "w") as f:
+        json.dump({"type": "node_collection", "children": children}, f)
+    scene = P.Scene.load(fuzz_root, "./many.json")
+    assert scene.desc.material_count == n_materials
+    gpu = P.HipRenderer.init(scene, 0)
+    cpu = oracle.scene(scene.desc_pointer)
+    task = P.RenderTask(scene="./many.json", config=P.Config(trace_depth=6, iterations=3),
+                        camera=P.Camera(resolution=[96, 64], rotation=np.eye(3).tolist(), position=[0.0, 1.0, 14.0], fov=0.9,
+                                        near_plane=0.0, focal_length=12.0, bokeh_shape="circle", bokeh_size=0.2))
+    opts = P.RenderOpts(seed=9)
+    img = gpu.render(task, opts)
+    ref, st = cpu.render(task, opts, accel=ob.ACCEL_LINEAR, math=ob.MATH_PORTABLE)
+    assert gpu.last_stats.rays == st.rays
+    assert (H.bits(img) == H.bits(ref)).all()
+    rays = H.random_rays(5000, seed=n_materials)
+    H.assert_all_routes(gpu, rays, cpu.trace(rays, accel=ob.ACCEL_LINEAR, math=ob.MATH_PORTABLE), f"{n_materials} materials")
+    gpu.close()
+    cpu.close()
