@@ -531,8 +531,14 @@ walk_kernel(RenderParams p, SegmentBuffers b, uint32_t cap, uint32_t regions, un
 #ifndef PT_BOUNCE_OCCUPANCY
 #define PT_BOUNCE_OCCUPANCY 5
 #endif
+// With the instance-run listing the kernel is asked for three waves per SIMD: the compiler then takes 124 registers
+// and spills none (four waves fit after all); asked for five it takes 96 and spills 15, asked for four, 110 and none:
+// the 115-instance frame 64.0 / 63.6 / 62.0 ms at 5 / 4 / 3.
+#ifndef PT_BOUNCE_RUN_OCCUPANCY
+#define PT_BOUNCE_RUN_OCCUPANCY 3
+#endif
 template <bool kRun>
-__global__ void __launch_bounds__(kBlock, PT_BOUNCE_OCCUPANCY)
+__global__ void __launch_bounds__(kBlock, kRun ? PT_BOUNCE_RUN_OCCUPANCY : PT_BOUNCE_OCCUPANCY)
 bounce_kernel(RenderParams p, uint32_t depth, SegmentBuffers b, SearchList sl, uint32_t cap, uint32_t regions,
               float* contrib) {
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
