@@ -1400,6 +1400,9 @@ PtStatus pt_scene_create(const PtSceneDesc* desc, int device, PtScene** out_scen
             s->d.run.child_count = (uint32_t)run.children.size();
             s->d.run.first_node = run.first_node;
             s->d.run.end_node = run.end_node;
+            s->d.run.only_mesh = run.children[0].mesh_id;
+            for (const ptk::RunChild& c : run.children)
+                if (c.mesh_id != run.children[0].mesh_id) s->d.run.only_mesh = 0xFFFFFFFFu;
             s->run_slots = std::min<uint32_t>((uint32_t)run.children.size(), kRunSlotsPerRay);
         }
         hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");

@@ -740,7 +740,8 @@ __device__ __forceinline__ RunChildIds run_child_ids(const DRun& run, uint32_t k
     return ids;
 }
 __device__ __forceinline__ Ray run_child_ray(const DRun& run, uint32_t k, const RunChildIds& ids, const Ray& r) {
-    if (ids.transform_node == kRunNoTransform) return r;
+    // the rows are asked for whether or not the child has a transform (every record holds them): the answer to
+    // that is in the record too, and waiting for it first would be a second trip to memory
     M4 inv;
     M3 ninv;
     unpack_rows(global_f4(run.children + k), 1, &inv, &ninv);
@@ -754,7 +755,7 @@ __device__ __forceinline__ Ray run_child_ray(const DRun& run, uint32_t k, const 
     o.direction = mul(ninv, r.direction);
     o.min = length(mn - s);
     o.max = length(mx - s);
-    return o;
+    return ids.transform_node == kRunNoTransform ? r : o;
 }
 
 // What the run's child k returns for `world` (transform.rs:45-66 around

@@ -193,6 +193,9 @@ __device__ __forceinline__ uint32_t list_searches(const DScene& scene, const Sea
     __shared__ uint32_t run_pairs[kBlock / 64][kPairs];
     __shared__ uint32_t run_heads[kBlock / 64][64];
     const uint32_t lane = (uint32_t)__popcll(lane_lt), w = threadIdx.x >> 6;
+    // where every child places the same mesh, its bounds are read once, by scalar loads, instead of per pair
+    const bool one_mesh = scene.run.only_mesh != 0xFFFFFFFFu;
+    const DMesh run_mesh = uniform_mesh(scene, one_mesh ? scene.run.only_mesh : 0u);
     RunCursor cursor;
     run_begin(scene.run, world, queued, cursor);
     run_heads[w][lane] = kRunNone;
@@ -230,7 +233,7 @@ __device__ __forceinline__ uint32_t list_searches(const DScene& scene, const Sea
                 const RunChildIds ids = run_child_ids(scene.run, child);
                 mesh_id = ids.mesh_id;
                 ray = run_child_ray(scene.run, child, ids, theirs);
-                need = trav_reaches(scene.meshes[mesh_id], ray);
+                need = one_mesh ? trav_reaches(run_mesh, ray) : trav_reaches(scene.meshes[mesh_id], ray);
             }
             const unsigned long long mask = __ballot(need);
             const uint32_t wanted = (uint32_t)__popcll(mask);

@@ -165,6 +165,7 @@ struct DRun {
     uint32_t child_count;     // 0: the scene has no run
     uint32_t first_node;      // node index of the first child
     uint32_t end_node;        // one past the last child's subtree
+    uint32_t only_mesh;       // the mesh every child places, 0xFFFFFFFF when they place different ones
 };
 // A ray's searches within the run form a chain through the job list: job_c.w of
 // a job = the previous job of the same ray (index within the region), the ray's
