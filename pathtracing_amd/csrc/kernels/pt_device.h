@@ -784,8 +784,8 @@ __device__ __forceinline__ void run_child_hit(const DScene& sc, uint32_t k, cons
 // The distance at which the run's child k reports the triangle hit at `t` in its mesh's space: the t of
 // run_child_hit's record (transform.rs:57-58 on the point of triangle_finish) without the rest of it.
 __device__ __forceinline__ float run_child_distance(const DScene& sc, uint32_t k, const Ray& world, float t) {
+    // ids and rows in one trip (run_child_ray)
     const RunChildIds ids = run_child_ids(sc.run, k);
-    if (ids.transform_node == kRunNoTransform) return t;
     M4 inv, fwd;
     M3 ninv, nfwd;
     unpack_rows(global_f4(sc.run.children + k), 1, &inv, &ninv);
@@ -793,7 +793,7 @@ __device__ __forceinline__ float run_child_distance(const DScene& sc, uint32_t k
     V3 source = mul_point(inv, world.source);
     V3 direction = mul(ninv, world.direction);
     V3 point = mul_point(fwd, source + direction * t);
-    return length(point - world.source);
+    return ids.transform_node == kRunNoTransform ? t : length(point - world.source);
 }
 
 // node_collection.rs:48-52 over the children of the run: `h` of child k replaces the
