@@ -89,6 +89,31 @@ def test_dragon_render_bit_exact(dragon):
     assert got.mean() > 0.01
 
 
+def test_dragon_full_frame_is_the_same_however_it_is_scheduled(dragon):
+    """The 1920x1080 frame (regions of thousands of rays, hundreds of 64-ray chunks each: the sizes the walk + bounce
+    kernel's read-ahead into LDS works at) rendered three times with the default settings, one batch at a time, and in
+    batches of three million paths: the same bits every time, and the same rays counted."""
+    task, gpu, cpu = dragon
+    task.camera.resolution = [1920, 1080]
+    task.config.iterations = 6
+    first = gpu.render(task, P.RenderOpts(seed=3))
+    rays = gpu.last_stats.rays
+    for opts in (P.RenderOpts(seed=3), P.RenderOpts(seed=3), P.RenderOpts(seed=3, single_stream=True),
+                 P.RenderOpts(seed=3, paths_per_batch=3_000_000), P.RenderOpts(seed=3, paths_per_batch=128 << 20, single_stream=True)):
+        again = gpu.render(task, opts)
+        assert gpu.last_stats.rays == rays
+        assert np.array_equal(H.bits(again), H.bits(first))
+    # and a strip of it against the oracle
+    strip = P.RenderOpts(seed=3, tile=(900, 500, 96, 8))
+    want, st = cpu.render(task, strip, accel=ob.ACCEL_BVH, math=ob.MATH_PORTABLE)
+    got = gpu.render(task, strip)
+    assert gpu.last_stats.rays == st.rays
+    assert np.array_equal(H.bits(got), H.bits(want))
+    rows = slice(1080 - 508, 1080 - 500) # images come top row first
+    assert got[rows, 900:996].any() and not got[:rows.start].any() and not got[rows.stop:].any()
+    assert np.array_equal(H.bits(got[rows, 900:996]), H.bits(first[rows, 900:996]))
+
+
 def test_dragon_rays_along_coordinate_planes(dragon):
     """Directions with components that are exactly zero (mirror bounces off the box
     walls produce them): 1/direction is infinite on those axes, which the search's
