@@ -130,7 +130,8 @@ def test_discovery_datagrams_are_answered_with_the_websocket_port(served):
         assert reply == F.discovery_response_bytes(server.websocket_port)
         assert F.discovery_response_port(reply) == server.websocket_port
     s.close()
-    assert server.stats()["datagrams_answered"] == 4
+    # the responder counts a datagram after it has sent the reply
+    assert wait_for(lambda: server.stats()["datagrams_answered"] == 4)
 
 
 def test_websocket_upgrade_follows_rfc6455(served):
@@ -294,8 +295,8 @@ def test_render_tasks_over_the_websocket(tmp_path):
         c.send_frame(0x1, json.dumps(wire).encode())
         assert c.recv_frame() == (0x2, replies[1])
         c.close()
-        st = server.stats()
-        assert st["messages_answered"] == 3 and st["messages_failed"] == 1 and worker.cached_scene_count == 1
+        assert wait_for(lambda: server.stats()["messages_answered"] == 3) # counted after the reply has been sent
+        assert server.stats()["messages_failed"] == 1 and worker.cached_scene_count == 1
     worker.close()
 
 
