@@ -756,9 +756,23 @@ void render_accumulate(PtScene* scene, const PtRenderTask* task, const PtRenderO
         samples_per_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / band_slots, task->iterations ? task->iterations : 1));
         // a batch indexes its path slots with 32 bits
         while ((uint64_t)samples_per_batch * band_slots > 0xFFFFFFFFull && samples_per_batch > 1) samples_per_batch /= 2;
+        flight = (profile || count_visits || (o.flags & PT_FLAG_SINGLE_STREAM)) ? 1 : batches_in_flight_allowed();
+        // The samples go into batches of equal size (64 as 22 + 22 + 20, not 30 + 30 + 4), and a render that one
+        // batch would hold is cut into two when two may be in flight and each half is still a big launch: two
+        // batches of 8 Mi paths side by side beat one of 16 Mi by 6 %, two of 16 Mi one of 32 Mi by 9 %, two of 32 Mi one
+        // of 64 Mi by 11 %; below 8 Mi in all it makes no difference (tools/probe_samples.py).  This is what a rank of a
+        // frame shared among GPUs by sample ranges renders.
+        {
+            uint64_t sample_batches = (task->iterations + samples_per_batch - 1) / samples_per_batch;
+            const bool one_band = band_block_rows >= total_block_rows;
+            if (sample_batches == 1 && one_band && flight > 1 && !o.paths_per_batch && task->iterations >= 2 &&
+                band_slots * task->iterations >= (8ull << 20))
+                sample_batches = 2;
+            if (sample_batches > 1)
+                samples_per_batch = (uint32_t)((task->iterations + sample_batches - 1) / sample_batches);
+        }
         const uint64_t n_batches = (uint64_t)((total_block_rows + band_block_rows - 1) / band_block_rows) *
                                    ((task->iterations + samples_per_batch - 1) / samples_per_batch);
-        flight = (profile || count_visits || (o.flags & PT_FLAG_SINGLE_STREAM)) ? 1 : batches_in_flight_allowed();
         flight = (int)std::min<uint64_t>((uint64_t)flight, std::max<uint64_t>(n_batches, 1));
         const uint64_t records = (uint64_t)ptk::queue_region_capacity(nbx, band_block_rows, samples_per_batch, waves) * waves;
         const uint64_t paths = band_slots * samples_per_batch;
