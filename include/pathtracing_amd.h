@@ -235,7 +235,11 @@ typedef struct PtRenderOpts {
     uint32_t flags;         /* PT_FLAG_*                                                    */
     uint32_t tile_x0, tile_y0, tile_w, tile_h; /* camera-space pixel rectangle to render
                                (y up); w==0 or h==0: whole frame.  Pixels outside stay 0.   */
-    uint32_t paths_per_batch; /* 0: library default                                         */
+    uint32_t paths_per_batch; /* path slots traced at a time (whole samples of a band of 8-pixel
+                               rows).  0: library default -- up to 64 Mi (16 Mi for scenes with an
+                               instance run), in batches of equal size, at least two of them when
+                               the render has 8 Mi paths or more (two are kept in flight).  The
+                               image does not depend on it.                                    */
 } PtRenderOpts;
 
 typedef struct PtRenderStats {
